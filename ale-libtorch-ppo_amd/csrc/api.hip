@@ -1,0 +1,1116 @@
+// api.hip - C ABI (include/aleppo.h) over the HIP kernels: context, rollout protocol, PPO update,
+// RCCL gradient all-reduce, parity read-back.  Host-side orchestration only; every number is produced
+// by a HIP kernel on the device - there is no CPU fallback (a missing device is ALEPPO_ERR_NO_DEVICE).
+#include "common.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <rccl/rccl.h>
+
+using namespace aleppo;
+
+namespace aleppo {
+
+static thread_local std::string g_err;
+int set_err(Ctx *c, int code, const std::string &msg) {
+  if (c)
+    c->err = msg;
+  g_err = msg;
+  return code;
+}
+
+// ------------------------------------------------------------------ parameter layout
+static inline size_t align64(size_t x) { return (x + 63) / 64 * 64; }
+void ParamLayout::init(int H_, int A_) {
+  H = H_;
+  A = A_;
+  size[P_WH] = (size_t)(A + 1) * H;
+  size[P_BH] = (size_t)A + 1;
+  size[P_WFC] = (size_t)H * FC_IN;
+  size[P_BFC] = (size_t)H;
+  size[P_W3] = 64 * 576;
+  size[P_B3] = 64;
+  size[P_W2] = 64 * 512;
+  size[P_B2] = 64;
+  size[P_W1] = 32 * 256;
+  size[P_B1] = 32;
+  off[0] = 0;
+  for (int i = 0; i < P_COUNT; ++i)
+    off[i + 1] = off[i] + align64(size[i]);
+  bucket0_end = off[P_W3];
+}
+size_t ParamLayout::reference_count() const {
+  size_t n = 0;
+  for (int i = 0; i < P_COUNT; ++i)
+    n += size[i];
+  return n;
+}
+
+// libtorch parameters() order: c1w[32,4,8,8] c1b c2w[64,32,4,4] c2b c3w[64,64,3,3] c3b fcw[H,3136] fcb aw[A,H] ab
+// vw[1,H] vb.  Internal: conv weights [oc][(kh,kw,c)]; fc weight columns in (y,x,c) order (NHWC flatten) instead
+// of libtorch's (c,y,x); heads stacked [A+1][H] (value head last).
+template <bool TO_INTERNAL> static void permute_params(const ParamLayout &L, const float *src, float *dst) {
+  const int H = L.H, A = L.A;
+  size_t r = 0; // running reference offset
+  auto conv = [&](int OC, int C, int KH, int KW, ParamId wid, ParamId bid) {
+    const size_t wn = (size_t)OC * C * KH * KW;
+    for (int oc = 0; oc < OC; ++oc)
+      for (int c = 0; c < C; ++c)
+        for (int kh = 0; kh < KH; ++kh)
+          for (int kw = 0; kw < KW; ++kw) {
+            const size_t ri = r + (((size_t)oc * C + c) * KH + kh) * KW + kw;
+            const size_t ii = L.off[wid] + (size_t)oc * (KH * KW * C) + (size_t)(kh * KW + kw) * C + c;
+            if (TO_INTERNAL)
+              dst[ii] = src[ri];
+            else
+              dst[ri] = src[ii];
+          }
+    r += wn;
+    for (int oc = 0; oc < OC; ++oc) {
+      if (TO_INTERNAL)
+        dst[L.off[bid] + oc] = src[r + oc];
+      else
+        dst[r + oc] = src[L.off[bid] + oc];
+    }
+    r += OC;
+  };
+  conv(32, 4, 8, 8, P_W1, P_B1);
+  conv(64, 32, 4, 4, P_W2, P_B2);
+  conv(64, 64, 3, 3, P_W3, P_B3);
+  for (int o = 0; o < H; ++o)
+    for (int c = 0; c < 64; ++c)
+      for (int p = 0; p < 49; ++p) {
+        const size_t ri = r + (size_t)o * FC_IN + c * 49 + p, ii = L.off[P_WFC] + (size_t)o * FC_IN + p * 64 + c;
+        if (TO_INTERNAL)
+          dst[ii] = src[ri];
+        else
+          dst[ri] = src[ii];
+      }
+  r += (size_t)H * FC_IN;
+  auto lin = [&](size_t n, size_t ioff) {
+    for (size_t i = 0; i < n; ++i) {
+      if (TO_INTERNAL)
+        dst[ioff + i] = src[r + i];
+      else
+        dst[r + i] = src[ioff + i];
+    }
+    r += n;
+  };
+  lin(H, L.off[P_BFC]);
+  lin((size_t)A * H, L.off[P_WH]);          // action_head.weight
+  lin(A, L.off[P_BH]);                      // action_head.bias
+  lin(H, L.off[P_WH] + (size_t)A * H);      // value_head.weight
+  lin(1, L.off[P_BH] + A);                  // value_head.bias
+}
+void params_to_internal(const ParamLayout &L, const float *ref, float *internal) {
+  std::fill(internal, internal + L.total(), 0.0f);
+  permute_params<true>(L, ref, internal);
+}
+void params_to_reference(const ParamLayout &L, const float *internal, float *ref) {
+  permute_params<false>(L, internal, ref);
+}
+
+} // namespace aleppo
+
+// ------------------------------------------------------------------ helpers
+#define CHECK_CTX(c)                                                                                                   \
+  if (!(c))                                                                                                            \
+  return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "null context")
+#define NCCLCHK(c, x)                                                                                                  \
+  do {                                                                                                                 \
+    ncclResult_t r_ = (x);                                                                                             \
+    if (r_ != ncclSuccess)                                                                                             \
+      return set_err((c), ALEPPO_ERR_HIP, std::string(#x) + ": " + ncclGetErrorString(r_));                            \
+  } while (0)
+
+static size_t tsz(const Ctx *c) { return c->prec == ALEPPO_BF16 ? 2 : 4; }
+template <class T> static hipError_t dalloc(T **p, size_t bytes) {
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes ? bytes : 16);
+  if (e == hipSuccess)
+    e = hipMemset(*p, 0, bytes ? bytes : 16);
+  return e;
+}
+
+static void prof_begin(Ctx *c, int cls) {
+  if (!c->prof_on)
+    return;
+  ProfClass &p = c->prof[cls];
+  if (p.used == p.start.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    p.start.push_back(a);
+    p.stop.push_back(b);
+  }
+  hipEventRecord(p.start[p.used], c->stream);
+}
+static void prof_end(Ctx *c, int cls) {
+  if (!c->prof_on)
+    return;
+  ProfClass &p = c->prof[cls];
+  hipEventRecord(p.stop[p.used], c->stream);
+  p.used++;
+}
+
+static SampleMap train_map(const Ctx *c, long n0) {
+  // sample n = e*T + t lives in slot (e, t) of obs [E][T+1][7056]
+  return SampleMap{c->T, (long)(c->T + 1) * FRAME_PIX, (long)FRAME_PIX, 0, (int)n0};
+}
+static SampleMap slot_map(const Ctx *c, int t) {
+  return SampleMap{1, (long)(c->T + 1) * FRAME_PIX, 0, (long)t * FRAME_PIX, 0};
+}
+
+static const float *Pf(const Ctx *c, ParamId id) { return c->P + c->L.off[id]; }
+static const void *Pcw(const Ctx *c, ParamId id) {
+  return static_cast<const char *>(c->Pc) + c->L.off[id] * tsz(c);
+}
+
+// conv stack forward for ns samples addressed by map -> c->h
+static void net_forward(Ctx *c, SampleMap map, long ns) {
+  prof_begin(c, ALEPPO_K_CONV1_FWD);
+  conv1_fwd(c->stream, c->prec, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, ns);
+  prof_end(c, ALEPPO_K_CONV1_FWD);
+  prof_begin(c, ALEPPO_K_CONV2_FWD);
+  conv2_fwd(c->stream, c->prec, c->a1, Pcw(c, P_W2), Pf(c, P_B2), c->a2, ns);
+  prof_end(c, ALEPPO_K_CONV2_FWD);
+  prof_begin(c, ALEPPO_K_CONV3_FWD);
+  conv3_fwd(c->stream, c->prec, c->a2, Pcw(c, P_W3), Pf(c, P_B3), c->a3, ns);
+  prof_end(c, ALEPPO_K_CONV3_FWD);
+  prof_begin(c, ALEPPO_K_FC_FWD);
+  fc_fwd(c->stream, c->prec, c->a3, Pcw(c, P_WFC), Pf(c, P_BFC), c->h, ns, c->H);
+  prof_end(c, ALEPPO_K_FC_FWD);
+}
+
+static void refresh_compute_copies(Ctx *c) {
+  if (c->prec == ALEPPO_BF16)
+    launch_cast_params(c->stream, c->P, c->Pc, (long)c->L.total());
+  launch_pack_dgrad(c->stream, c->P, c->L, c->W2d, c->W3d, c->WfcT, c->prec);
+}
+
+// ------------------------------------------------------------------ lifetime
+extern "C" int aleppo_abi_version(void) { return ALEPPO_ABI_VERSION; }
+extern "C" const char *aleppo_last_error(const aleppo_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+static int select_device(int ordinal) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return set_err(nullptr, ALEPPO_ERR_NO_DEVICE,
+                   "no HIP device visible: libaleppo has no CPU fallback (needs an MI355X / gfx950)");
+  if (ordinal < 0 || ordinal >= n)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "device_ordinal out of range");
+  if (hipSetDevice(ordinal) != hipSuccess)
+    return set_err(nullptr, ALEPPO_ERR_HIP, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess)
+    return set_err(nullptr, ALEPPO_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_err(nullptr, ALEPPO_ERR_NO_DEVICE,
+                   std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
+  if (!cfg || !out)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != ALEPPO_ABI_VERSION)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "abi_version mismatch");
+  // same checks as Rollout::Rollout (rollout.cc:48-59) where they apply
+  if (cfg->num_envs <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "Total environments must be greater than 0.");
+  if (cfg->horizon <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "Horizon must be greater than 0.");
+  if (cfg->frame_stack != 4)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "frame_stack must be 4 (conv1 has 4 input channels)");
+  if (cfg->num_actions < 1 || cfg->num_actions > MAX_ACTIONS)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "num_actions must be in [1,18]");
+  if (cfg->hidden_size < 32 || cfg->hidden_size > 512 || cfg->hidden_size % 32)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "hidden_size must be a multiple of 32 in [32,512]");
+  if (cfg->precision != ALEPPO_FP32 && cfg->precision != ALEPPO_BF16)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "precision must be ALEPPO_FP32 or ALEPPO_BF16");
+  if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad world_size / rank");
+  int rc = select_device(cfg->device_ordinal);
+  if (rc)
+    return rc;
+
+  aleppo_ctx *c = new aleppo_ctx();
+  c->cfg = *cfg;
+  if (c->cfg.adam_beta1 == 0.f)
+    c->cfg.adam_beta1 = 0.9f;
+  if (c->cfg.adam_beta2 == 0.f)
+    c->cfg.adam_beta2 = 0.999f;
+  if (c->cfg.adam_eps == 0.f)
+    c->cfg.adam_eps = 1e-5f;
+  c->E = cfg->num_envs;
+  c->T = cfg->horizon;
+  c->A = cfg->num_actions;
+  c->H = cfg->hidden_size;
+  c->prec = cfg->precision;
+  c->world = cfg->world_size;
+  c->rank = cfg->rank;
+  c->N = (long)c->E * c->T;
+  c->maxB = cfg->max_minibatch > 0 ? std::max<long>(cfg->max_minibatch, c->E) : std::max<long>(c->N, c->E);
+  c->L.init(c->H, c->A);
+  const int E = c->E, T = c->T, A = c->A, H = c->H;
+  const size_t ts = tsz(c), PT = c->L.total();
+#define CK(x)                                                                                                          \
+  do {                                                                                                                 \
+    hipError_t e_ = (x);                                                                                               \
+    if (e_ != hipSuccess) {                                                                                            \
+      set_err(nullptr, ALEPPO_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                               \
+      aleppo_destroy(c);                                                                                               \
+      return ALEPPO_ERR_HIP;                                                                                           \
+    }                                                                                                                  \
+  } while (0)
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  CK(hipEventCreateWithFlags(&c->ev_bucket0, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_comm0, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_comm1, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_tmp, hipEventDisableTiming));
+  CK(dalloc(&c->obs, (size_t)E * (T + 1) * FRAME_PIX * 4));
+  c->step_rec_bytes = ((size_t)7 * E + 15) / 16 * 16;
+  CK(dalloc(&c->step_rec, c->step_rec_bytes * T));
+  CK(dalloc(&c->values_tm, (size_t)(T + 1) * E * 4));
+  CK(dalloc(&c->logits_tm, (size_t)(T + 1) * E * A * 4));
+  CK(dalloc(&c->actions_tm, (size_t)(T + 1) * E * 4));
+  CK(dalloc(&c->lut, 256));
+  CK(dalloc(&c->d_start, (size_t)E));
+  CK(dalloc(&c->d_frames, (size_t)E * 2 * RAW_H * RAW_W));
+  CK(dalloc(&c->d_noise, (size_t)E * A * 4));
+  CK(dalloc(&c->d_err, 16));
+  {
+    uint8_t ident[256];
+    for (int i = 0; i < 256; ++i)
+      ident[i] = (uint8_t)i;
+    CK(hipMemcpy(c->lut, ident, 256, hipMemcpyHostToDevice));
+  }
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_actions), (size_t)E * 8, hipHostMallocMapped));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_step), c->step_rec_bytes + E, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_frames), (size_t)E * 2 * RAW_H * RAW_W, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_noise), (size_t)E * A * 4, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), 16, hipHostMallocDefault));
+  std::memset(c->h_actions, 0, (size_t)E * 8);
+  CK(dalloc(&c->adv_n, (size_t)c->N * 4));
+  CK(dalloc(&c->ret_n, (size_t)c->N * 4));
+  CK(dalloc(&c->oldlp_n, (size_t)c->N * A * 4));
+  CK(dalloc(&c->act_n, (size_t)c->N * 4));
+  CK(dalloc(&c->mask_n, (size_t)c->N));
+  CK(dalloc(&c->mask_counts, 4096 * 4));
+  CK(dalloc(&c->P, PT * 4));
+  CK(dalloc(&c->G, PT * 4));
+  CK(dalloc(&c->Gs, PT * 4));
+  CK(dalloc(&c->M1, PT * 4));
+  CK(dalloc(&c->M2, PT * 4));
+  if (c->prec == ALEPPO_BF16)
+    CK(dalloc(reinterpret_cast<char **>(&c->Pc), PT * 2));
+  else
+    c->Pc = c->P;
+  CK(dalloc(reinterpret_cast<char **>(&c->W2d), (size_t)4 * 32 * 256 * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->W3d), (size_t)64 * 576 * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->WfcT), (size_t)FC_IN * H * ts));
+  const size_t mb = (size_t)c->maxB;
+  CK(dalloc(reinterpret_cast<char **>(&c->a1), mb * A1_PIX * A1_C * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->a2), mb * A2_PIX * A2_C * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->a3), mb * FC_IN * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->dz1), mb * A1_PIX * A1_C * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->dz2), mb * A2_PIX * A2_C * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->dz3), mb * FC_IN * ts));
+  CK(dalloc(&c->h, mb * H * 4));
+  CK(dalloc(reinterpret_cast<char **>(&c->dh), mb * H * ts));
+  CK(dalloc(&c->logits_b, mb * A * 4));
+  CK(dalloc(&c->values_b, mb * 4));
+  // slabs: [W1|b1|W2|b2|W3|b3|Wfc|bfc|Wh|bh]
+  c->slab_off[0] = 0;
+  const size_t sl[10] = {(size_t)MAXS_C1 * 32 * 256,       (size_t)MAXS_C1 * 32, (size_t)MAXS_C2 * 64 * 512,
+                         (size_t)MAXS_C2 * 64,              (size_t)MAXS_C3 * 64 * 576, (size_t)MAXS_C3 * 64,
+                         (size_t)MAXS_FC * H * FC_IN,       (size_t)MAXS_FC * H, (size_t)MAXS_HEAD * (A + 1) * H,
+                         (size_t)MAXS_HEAD * (A + 1)};
+  for (int i = 0; i < 10; ++i)
+    c->slab_off[i + 1] = c->slab_off[i] + align64(sl[i]);
+  c->slab_floats = c->slab_off[10];
+  CK(dalloc(&c->slab, c->slab_floats * 4));
+  CK(dalloc(&c->sumsq_part, 1024 * 4));
+  CK(dalloc(&c->adv_stats, 64));
+  CK(hipDeviceSynchronize());
+#undef CK
+  *out = c;
+  return ALEPPO_OK;
+}
+
+extern "C" void aleppo_destroy(aleppo_ctx *c) {
+  if (!c)
+    return;
+  hipDeviceSynchronize();
+  if (c->nccl_comm)
+    ncclCommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
+  void *dev[] = {c->obs,   c->step_rec, c->values_tm, c->logits_tm, c->actions_tm, c->lut,     c->d_start,
+                 c->d_frames, c->d_noise, c->d_err,  c->adv_n,     c->ret_n,      c->oldlp_n, c->act_n,
+                 c->mask_n, c->mask_counts, c->P,    c->G,         c->Gs,         c->M1,      c->M2,
+                 c->W2d,   c->W3d,      c->WfcT,      c->a1,        c->a2,         c->a3,      c->dz1,
+                 c->dz2,   c->dz3,      c->h,         c->dh,        c->logits_b,   c->values_b, c->slab,
+                 c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats};
+  for (void *p : dev)
+    if (p)
+      hipFree(p);
+  if (c->Pc && c->Pc != c->P)
+    hipFree(c->Pc);
+  void *host[] = {c->h_actions, c->h_step, c->h_frames, c->h_noise, c->h_err, c->h_metric_red};
+  for (void *p : host)
+    if (p)
+      hipHostFree(p);
+  for (auto &pc : c->prof)
+    for (size_t i = 0; i < pc.start.size(); ++i) {
+      hipEventDestroy(pc.start[i]);
+      hipEventDestroy(pc.stop[i]);
+    }
+  for (hipEvent_t e : {c->ev_bucket0, c->ev_comm0, c->ev_comm1, c->ev_tmp})
+    if (e)
+      hipEventDestroy(e);
+  if (c->stream)
+    hipStreamDestroy(c->stream);
+  if (c->comm_stream)
+    hipStreamDestroy(c->comm_stream);
+  delete c;
+}
+
+extern "C" int aleppo_synchronize(aleppo_ctx *c) {
+  CHECK_CTX(c);
+  HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ALEPPO_OK;
+}
+
+// ------------------------------------------------------------------ parameters
+extern "C" int aleppo_param_count(const aleppo_ctx *c, size_t *count) {
+  CHECK_CTX(c);
+  if (!count)
+    return ALEPPO_ERR_INVALID_ARGUMENT;
+  *count = c->L.reference_count();
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_load_params(aleppo_ctx *c, const float *flat, size_t count) {
+  CHECK_CTX(c);
+  if (!flat || count != c->L.reference_count())
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "load_params: wrong element count");
+  std::vector<float> tmp(c->L.total());
+  params_to_internal(c->L, flat, tmp.data());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->P, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(c->M1, 0, tmp.size() * 4));
+  HIPCHK(c, hipMemset(c->M2, 0, tmp.size() * 4));
+  HIPCHK(c, hipMemset(c->G, 0, tmp.size() * 4));
+  c->adam_step = 0;
+  refresh_compute_copies(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ALEPPO_OK;
+}
+static int export_flat(aleppo_ctx *c, const float *dev, float *flat, size_t count) {
+  if (!flat || count != c->L.reference_count())
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "export: wrong element count");
+  std::vector<float> tmp(c->L.total());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
+  params_to_reference(c->L, tmp.data(), flat);
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_export_params(aleppo_ctx *c, float *flat, size_t count) {
+  CHECK_CTX(c);
+  return export_flat(c, c->P, flat, count);
+}
+extern "C" int aleppo_export_grads(aleppo_ctx *c, float *flat, size_t count) {
+  CHECK_CTX(c);
+  return export_flat(c, c->Gs, flat, count);
+}
+
+// ------------------------------------------------------------------ rollout
+static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst, float *values_dst, int *actions_dst) {
+  net_forward(c, slot_map(c, slot), c->E);
+  const float *dn = nullptr;
+  if (noise) {
+    std::memcpy(c->h_noise, noise, (size_t)c->E * c->A * 4);
+    HIPCHK(c, hipMemcpyAsync(c->d_noise, c->h_noise, (size_t)c->E * c->A * 4, hipMemcpyHostToDevice, c->stream));
+    dn = c->d_noise;
+  }
+  int64_t *pinned_dev = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), c->h_actions, 0));
+  prof_begin(c, ALEPPO_K_INFER_HEAD);
+  launch_infer_head(c->stream, c->h, Pf(c, P_WH), Pf(c, P_BH), dn, c->cfg.seed, c->rng_counter++, logits_dst,
+                    values_dst, actions_dst, pinned_dev, c->E, c->H, c->A);
+  prof_end(c, ALEPPO_K_INFER_HEAD);
+  HIPCHK(c, hipGetLastError());
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **actions_pinned) {
+  CHECK_CTX(c);
+  if (c->t >= c->T)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
+  if (c->t == 0 && c->need_carry) { // slot T of the previous rollout is this rollout's first observation
+    launch_copy_slot(c->stream, c->obs, c->E, c->T + 1, c->T, 0);
+    c->need_carry = false;
+  }
+  const size_t o = (size_t)c->t * c->E;
+  int rc = do_act(c, noise, c->t, c->logits_tm + o * c->A, c->values_tm + o, c->actions_tm + o);
+  if (rc)
+    return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // actions are now visible in pinned host memory
+  if (actions_pinned)
+    *actions_pinned = c->h_actions;
+  return ALEPPO_OK;
+}
+
+static int upload_frames(aleppo_ctx *c, const uint8_t *frames, int kind, int location, const uint8_t **dev_frames) {
+  const size_t bytes = (size_t)c->E * (kind == ALEPPO_FRAMES_RAW_PAIR ? 2 * RAW_H * RAW_W : FRAME_PIX);
+  if (location == ALEPPO_DEVICE) {
+    if (reinterpret_cast<uintptr_t>(frames) % 16)
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "device frames must be 16-byte aligned");
+    *dev_frames = frames;
+    return ALEPPO_OK;
+  }
+  std::memcpy(c->h_frames, frames, bytes);
+  HIPCHK(c, hipMemcpyAsync(c->d_frames, c->h_frames, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev_frames = c->d_frames;
+  return ALEPPO_OK;
+}
+
+static int do_push(aleppo_ctx *c, const uint8_t *frames, int kind, int location, const uint8_t *episode_start) {
+  if (!frames || !episode_start)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (kind != ALEPPO_FRAMES_84 && kind != ALEPPO_FRAMES_RAW_PAIR)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown frame kind");
+  if (c->t >= c->T)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
+  // staging buffers are reused every step: wait for the previous upload (normally long finished: act() syncs)
+  HIPCHK(c, hipEventSynchronize(c->ev_tmp));
+  uint8_t *hs = c->h_step + c->step_rec_bytes;
+  std::memcpy(hs, episode_start, c->E);
+  HIPCHK(c, hipMemcpyAsync(c->d_start, hs, c->E, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *df = nullptr;
+  int rc = upload_frames(c, frames, kind, location, &df);
+  if (rc)
+    return rc;
+  prof_begin(c, ALEPPO_K_INGEST);
+  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, c->d_start, c->obs, c->E, c->T + 1, c->t,
+                c->t + 1);
+  prof_end(c, ALEPPO_K_INGEST);
+  HIPCHK(c, hipGetLastError());
+  return ALEPPO_OK;
+}
+static int do_record(aleppo_ctx *c, const float *rewards, const uint8_t *terminated, const uint8_t *truncated,
+                     const uint8_t *episode_start) {
+  if (!rewards || !terminated || !truncated || !episode_start)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (c->t >= c->T)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
+  const int E = c->E;
+  std::memcpy(c->h_step, rewards, (size_t)E * 4);
+  std::memcpy(c->h_step + 4 * (size_t)E, terminated, E);
+  std::memcpy(c->h_step + 5 * (size_t)E, truncated, E);
+  std::memcpy(c->h_step + 6 * (size_t)E, episode_start, E);
+  HIPCHK(c, hipMemcpyAsync(c->step_rec + (size_t)c->t * c->step_rec_bytes, c->h_step, (size_t)7 * E,
+                           hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
+  c->t++;
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_push_frames(aleppo_ctx *c, const uint8_t *frames, int kind, int location,
+                                  const uint8_t *episode_start) {
+  CHECK_CTX(c);
+  int rc = do_push(c, frames, kind, location, episode_start);
+  if (rc == ALEPPO_OK)
+    HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
+  return rc;
+}
+extern "C" int aleppo_record_step(aleppo_ctx *c, const float *rewards, const uint8_t *terminated,
+                                  const uint8_t *truncated, const uint8_t *episode_start) {
+  CHECK_CTX(c);
+  HIPCHK(c, hipEventSynchronize(c->ev_tmp));
+  return do_record(c, rewards, terminated, truncated, episode_start);
+}
+extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int location, const float *rewards,
+                           const uint8_t *terminated, const uint8_t *truncated, const uint8_t *episode_start) {
+  CHECK_CTX(c);
+  int rc = do_push(c, frames, kind, location, episode_start);
+  if (rc)
+    return rc;
+  return do_record(c, rewards, terminated, truncated, episode_start);
+}
+extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
+  CHECK_CTX(c);
+  if (!lut256)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null lut");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->lut, lut256, 256, hipMemcpyHostToDevice));
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
+  CHECK_CTX(c);
+  if (c->t != c->T)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "Buffer is not full, cannot compute GAE."); // buffer.cc:64-65
+  const int E = c->E, T = c->T, A = c->A;
+  // extra selector call on the post-rollout observation: its values bootstrap slot T-1, its sample is
+  // discarded but advances the RNG stream like the reference (rollout.cc:268-270)
+  int rc = do_act(c, noise, T, c->logits_tm + (size_t)T * E * A, c->values_tm + (size_t)T * E,
+                  c->actions_tm + (size_t)T * E);
+  if (rc)
+    return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_err, 0, 4, c->stream));
+  prof_begin(c, ALEPPO_K_GAE);
+  launch_gae(c->stream, c->step_rec, c->step_rec_bytes, c->values_tm, c->logits_tm, c->actions_tm, c->adv_n, c->ret_n,
+             c->oldlp_n, c->act_n, c->mask_n, c->d_err, E, T, A, c->cfg.gamma, c->cfg.lambda);
+  prof_end(c, ALEPPO_K_GAE);
+  if (c->cfg.advantage_norm) {
+    launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 0);
+    if (c->world > 1 && c->nccl_comm)
+      NCCLCHK(c, ncclAllReduce(c->adv_stats, c->adv_stats, 3, ncclFloat, ncclSum,
+                               static_cast<ncclComm_t>(c->nccl_comm), c->stream));
+    launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 1);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->t = 0;
+  c->need_carry = true;
+  c->batch_n = c->N;
+  if (*c->h_err)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT,
+                   "Episode starts, terminals, and truncations must be mutually exclusive."); // gae.cc:49-53
+  return ALEPPO_OK;
+}
+
+// ------------------------------------------------------------------ update
+static int ensure_metric_storage(aleppo_ctx *c, int epochs, int M, long B) {
+  const size_t need = (size_t)epochs * M * B;
+  if (need > c->metric_cap) {
+    if (c->metric_ps)
+      hipFree(c->metric_ps);
+    c->metric_ps = nullptr;
+    HIPCHK(c, dalloc(&c->metric_ps, need * 5 * 4));
+    c->metric_cap = need;
+  }
+  const size_t nm = (size_t)epochs * M;
+  if (nm > c->metric_red_cap) {
+    if (c->metric_red)
+      hipFree(c->metric_red);
+    if (c->grad_norms)
+      hipFree(c->grad_norms);
+    if (c->h_metric_red)
+      hipHostFree(c->h_metric_red);
+    c->metric_red = c->grad_norms = c->h_metric_red = nullptr;
+    HIPCHK(c, dalloc(&c->metric_red, nm * 8 * 4));
+    HIPCHK(c, dalloc(&c->grad_norms, nm * 4));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_metric_red), nm * 9 * 4, hipHostMallocDefault));
+    c->metric_red_cap = nm;
+  }
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_minibatch_metrics *out) {
+  CHECK_CTX(c);
+  if (epochs <= 0 || M <= 0)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "epochs and num_mini_batches must be positive");
+  const long N = c->batch_n;
+  if (N <= 0)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "no batch: call aleppo_finish_rollout or aleppo_set_batch first");
+  if (N % M != 0)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "Batch size must be divisible by num_mini_batches"); // train.h:140-143
+  const long B = N / M;
+  if (B > c->maxB)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "minibatch larger than config.max_minibatch");
+  if (M > 4096)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "num_mini_batches > 4096");
+  if (c->world > 1 && !c->nccl_comm)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "world_size > 1 but aleppo_comm_init was not called");
+  int rc = ensure_metric_storage(c, epochs, M, B);
+  if (rc)
+    return rc;
+  ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_comm);
+  const bool dp = c->world > 1;
+  const int H = c->H, A = c->A, prec = c->prec;
+  const ParamLayout &L = c->L;
+  hipStream_t s = c->stream;
+  const Hyper hp{c->cfg.clip_param, c->cfg.value_loss_coef, c->cfg.entropy_coef, c->cfg.max_gradient_norm};
+
+  launch_mask_count(s, c->mask_n, c->mask_counts, B, M);
+  if (dp) // N_m of the masked mean is the GLOBAL count
+    NCCLCHK(c, ncclAllReduce(c->mask_counts, c->mask_counts, M, ncclFloat, ncclSum, comm, s));
+
+  float *sW1 = c->slab + c->slab_off[0], *sB1 = c->slab + c->slab_off[1], *sW2 = c->slab + c->slab_off[2],
+        *sB2 = c->slab + c->slab_off[3], *sW3 = c->slab + c->slab_off[4], *sB3 = c->slab + c->slab_off[5],
+        *sWfc = c->slab + c->slab_off[6], *sBfc = c->slab + c->slab_off[7], *sWh = c->slab + c->slab_off[8],
+        *sBh = c->slab + c->slab_off[9];
+  const size_t fs = c->metric_cap; // field stride of the per-sample metric arrays
+  const int nblk_head = (int)std::min<long>(MAXS_HEAD, (B + 15) / 16);
+  const int nblk_sq = (int)std::min<size_t>(1024, (L.total() + 4095) / 4096);
+
+  for (int ep = 0; ep < epochs; ++ep)
+    for (int mb = 0; mb < M; ++mb) { // contiguous env-major slices; randperm unused (Q1)
+      const int mi = ep * M + mb;
+      const long n0 = (long)mb * B;
+      const SampleMap map = train_map(c, n0);
+      net_forward(c, map, B);
+      prof_begin(c, ALEPPO_K_HEAD);
+      launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, c->oldlp_n + n0 * A, c->adv_n + n0,
+                        c->ret_n + n0, c->mask_n + n0, c->mask_counts + mb, hp, c->dh, prec,
+                        c->metric_ps + 0 * fs + (size_t)mi * B, c->metric_ps + 1 * fs + (size_t)mi * B,
+                        c->metric_ps + 2 * fs + (size_t)mi * B, c->metric_ps + 3 * fs + (size_t)mi * B,
+                        c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr);
+      prof_end(c, ALEPPO_K_HEAD);
+      prof_begin(c, ALEPPO_K_FC_DGRAD);
+      fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
+      prof_end(c, ALEPPO_K_FC_DGRAD);
+      prof_begin(c, ALEPPO_K_FC_WGRAD);
+      const int Sfc = fc_wgrad(s, prec, c->dh, c->a3, sWfc, sBfc, B, H);
+      prof_end(c, ALEPPO_K_FC_WGRAD);
+      prof_begin(c, ALEPPO_K_REDUCE);
+      {
+        const ReduceSeg segs[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
+                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]},
+                                   {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
+                                   {sBfc, Sfc, (long)H, (long)L.off[P_BFC]}};
+        launch_reduce_slabs(s, segs, 4, c->G);
+      }
+      prof_end(c, ALEPPO_K_REDUCE);
+      if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs
+        HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
+        NCCLCHK(c, ncclAllReduce(c->G, c->G, L.bucket0_end, ncclFloat, ncclSum, comm, c->comm_stream));
+        HIPCHK(c, hipEventRecord(c->ev_comm0, c->comm_stream));
+      }
+      prof_begin(c, ALEPPO_K_CONV3_DGRAD);
+      conv3_dgrad(s, prec, c->dz3, c->W3d, c->a2, c->dz2, B);
+      prof_end(c, ALEPPO_K_CONV3_DGRAD);
+      prof_begin(c, ALEPPO_K_CONV3_WGRAD);
+      const int S3 = conv3_wgrad(s, prec, c->dz3, c->a2, sW3, sB3, B);
+      prof_end(c, ALEPPO_K_CONV3_WGRAD);
+      prof_begin(c, ALEPPO_K_CONV2_DGRAD);
+      conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
+      prof_end(c, ALEPPO_K_CONV2_DGRAD);
+      prof_begin(c, ALEPPO_K_CONV2_WGRAD);
+      const int S2 = conv2_wgrad(s, prec, c->dz2, c->a1, sW2, sB2, B);
+      prof_end(c, ALEPPO_K_CONV2_WGRAD);
+      prof_begin(c, ALEPPO_K_CONV1_WGRAD);
+      const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
+      prof_end(c, ALEPPO_K_CONV1_WGRAD);
+      prof_begin(c, ALEPPO_K_REDUCE);
+      {
+        const ReduceSeg segs[6] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
+                                   {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]},
+                                   {sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
+        launch_reduce_slabs(s, segs, 6, c->G);
+      }
+      prof_end(c, ALEPPO_K_REDUCE);
+      if (dp) {
+        HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
+        NCCLCHK(c, ncclAllReduce(c->G + L.bucket0_end, c->G + L.bucket0_end, L.total() - L.bucket0_end, ncclFloat,
+                                 ncclSum, comm, c->comm_stream));
+        HIPCHK(c, hipEventRecord(c->ev_comm1, c->comm_stream));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_comm0, 0));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_comm1, 0));
+      }
+      prof_begin(c, ALEPPO_K_ADAM);
+      launch_sumsq(s, c->G, (long)L.total(), c->sumsq_part, nblk_sq);
+      c->adam_step += 1;
+      const double b1 = c->cfg.adam_beta1, b2 = c->cfg.adam_beta2;
+      const double bc1 = 1.0 - std::pow(b1, (double)c->adam_step), bc2 = 1.0 - std::pow(b2, (double)c->adam_step);
+      launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, prec, (long)L.total(),
+                  c->sumsq_part, nblk_sq, hp.max_norm, (float)(lr / bc1), (float)std::sqrt(bc2), (float)b1, (float)b2,
+                  c->cfg.adam_eps, c->grad_norms + mi);
+      launch_pack_dgrad(s, c->P, L, c->W2d, c->W3d, c->WfcT, prec);
+      prof_end(c, ALEPPO_K_ADAM);
+    }
+  HIPCHK(c, hipGetLastError());
+  const int nm = epochs * M;
+  launch_metrics_reduce(s, c->metric_ps, fs, c->mask_n, B, M, epochs, c->metric_red);
+  if (dp)
+    NCCLCHK(c, ncclAllReduce(c->metric_red, c->metric_red, (size_t)nm * 8, ncclFloat, ncclSum, comm, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_metric_red, c->metric_red, (size_t)nm * 8 * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(c->h_metric_red + (size_t)nm * 8, c->grad_norms, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  c->last_epochs = epochs;
+  c->last_M = M;
+  c->last_B = B;
+  if (out)
+    for (int i = 0; i < nm; ++i) {
+      const float *r = c->h_metric_red + (size_t)i * 8;
+      const float cnt = r[5];
+      out[i].loss = r[0] / cnt;
+      out[i].clipped_loss = r[1] / cnt;
+      out[i].value_loss = r[2] / cnt;
+      out[i].entropy = r[3] / cnt;
+      out[i].ratio = r[4] / cnt;
+      out[i].mask_count = cnt;
+      out[i].grad_norm = c->h_metric_red[(size_t)nm * 8 + i];
+    }
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_read_train_metric(aleppo_ctx *c, int field, float *dst, size_t count) {
+  CHECK_CTX(c);
+  const size_t n = (size_t)c->last_epochs * c->last_M * c->last_B;
+  if (!dst || field < 0 || field > 4 || count != n || n == 0)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_train_metric: bad field or count");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(dst, c->metric_ps + (size_t)field * c->metric_cap, n * 4, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, const int64_t *actions,
+                                const float *log_probabilities, const float *advantages, const float *returns,
+                                const uint8_t *masks, int64_t n) {
+  CHECK_CTX(c);
+  if (!observations || !actions || !log_probabilities || !advantages || !returns || !masks)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (n <= 0 || n > c->N)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "set_batch: n must be in [1, E*T]");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint8_t *tmp = nullptr;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * 4 * FRAME_PIX));
+  HIPCHK(c, hipMemcpy(tmp, observations, (size_t)n * 4 * FRAME_PIX, hipMemcpyHostToDevice));
+  launch_obs_pack(c->stream, tmp, c->obs, n, train_map(c, 0));
+  std::vector<int> a32(n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (actions[i] < 0 || actions[i] >= c->A) {
+      hipFree(tmp);
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "action index out of range");
+    }
+    a32[i] = (int)actions[i];
+  }
+  HIPCHK(c, hipMemcpy(c->act_n, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->oldlp_n, log_probabilities, (size_t)n * c->A * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->adv_n, advantages, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->ret_n, returns, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->mask_n, masks, (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(tmp);
+  c->batch_n = n;
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_forward(aleppo_ctx *c, const uint8_t *observations, int64_t n, float *logits, float *values) {
+  CHECK_CTX(c);
+  if (!observations || !logits || !values)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (n <= 0 || n > c->maxB || n > c->N)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "forward: n exceeds capacity");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint8_t *tmp = nullptr;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * 4 * FRAME_PIX));
+  HIPCHK(c, hipMemcpy(tmp, observations, (size_t)n * 4 * FRAME_PIX, hipMemcpyHostToDevice));
+  launch_obs_pack(c->stream, tmp, c->obs, n, train_map(c, 0)); // NOTE: overwrites rollout observation slots
+  net_forward(c, train_map(c, 0), n);
+  launch_heads_fwd(c->stream, c->h, Pf(c, P_WH), Pf(c, P_BH), c->logits_b, c->values_b, n, c->H, c->A);
+  HIPCHK(c, hipMemcpyAsync(logits, c->logits_b, (size_t)n * c->A * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(values, c->values_b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(tmp);
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_read_batch(aleppo_ctx *c, int field, void *dst, size_t bytes) {
+  CHECK_CTX(c);
+  if (!dst)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null dst");
+  const int E = c->E, T = c->T, A = c->A;
+  const size_t N = (size_t)c->N;
+  hipStream_t s = c->stream;
+  size_t need = 0;
+  void *tmp = nullptr;
+  auto fin = [&](const void *src) -> int {
+    if (bytes != need) {
+      if (tmp)
+        hipFree(tmp);
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: wrong byte count");
+    }
+    hipError_t e = hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(s);
+    if (tmp)
+      hipFree(tmp);
+    if (e != hipSuccess)
+      return set_err(c, ALEPPO_ERR_HIP, hipGetErrorString(e));
+    return ALEPPO_OK;
+  };
+  auto transposed = [&](const void *src, size_t pitch, int inner, int elem) -> int {
+    need = N * inner * elem;
+    HIPCHK(c, hipMalloc(&tmp, need));
+    launch_transpose_tm_pitched(s, src, pitch, tmp, E, T, inner, elem);
+    return fin(tmp);
+  };
+  switch (field) {
+  case ALEPPO_F_OBSERVATIONS: {
+    need = N * 4 * FRAME_PIX;
+    HIPCHK(c, hipMalloc(&tmp, need));
+    launch_obs_unpack(s, c->obs, static_cast<uint8_t *>(tmp), (long)N, train_map(c, 0));
+    return fin(tmp);
+  }
+  case ALEPPO_F_CURRENT_OBS: {
+    need = (size_t)E * 4 * FRAME_PIX;
+    HIPCHK(c, hipMalloc(&tmp, need));
+    const int slot = (c->t == 0 && c->need_carry) ? T : c->t;
+    launch_obs_unpack(s, c->obs, static_cast<uint8_t *>(tmp), E, slot_map(c, slot));
+    return fin(tmp);
+  }
+  case ALEPPO_F_ACTIONS: {
+    need = N * 8;
+    if (bytes != need)
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: wrong byte count");
+    std::vector<int> a(N);
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipMemcpy(a.data(), c->act_n, N * 4, hipMemcpyDeviceToHost));
+    int64_t *o = static_cast<int64_t *>(dst);
+    for (size_t i = 0; i < N; ++i)
+      o[i] = a[i];
+    return ALEPPO_OK;
+  }
+  case ALEPPO_F_REWARDS:
+    return transposed(c->step_rec, c->step_rec_bytes, 1, 4);
+  case ALEPPO_F_TERMINALS:
+    return transposed(c->step_rec + 4 * (size_t)E, c->step_rec_bytes, 1, 1);
+  case ALEPPO_F_TRUNCATIONS:
+    return transposed(c->step_rec + 5 * (size_t)E, c->step_rec_bytes, 1, 1);
+  case ALEPPO_F_LOGITS:
+    return transposed(c->logits_tm, (size_t)E * A * 4, A, 4);
+  case ALEPPO_F_VALUES:
+    return transposed(c->values_tm, (size_t)E * 4, 1, 4);
+  case ALEPPO_F_MASKS:
+    need = N;
+    return fin(c->mask_n);
+  case ALEPPO_F_ADVANTAGES:
+    need = N * 4;
+    return fin(c->adv_n);
+  case ALEPPO_F_RETURNS:
+    need = N * 4;
+    return fin(c->ret_n);
+  case ALEPPO_F_LOG_PROBS:
+    need = N * A * 4;
+    return fin(c->oldlp_n);
+  case ALEPPO_F_NEXT_VALUES:
+    need = (size_t)E * 4;
+    return fin(c->values_tm + (size_t)T * E);
+  default:
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: unknown field");
+  }
+}
+
+// ------------------------------------------------------------------ multi-GPU
+extern "C" int aleppo_comm_unique_id(uint8_t id[ALEPPO_UNIQUE_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == ALEPPO_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess)
+    return set_err(nullptr, ALEPPO_ERR_HIP, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  std::memcpy(id, &u, sizeof(u));
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_comm_init(aleppo_ctx *c, const uint8_t id[ALEPPO_UNIQUE_ID_BYTES]) {
+  CHECK_CTX(c);
+  if (c->nccl_comm)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "communicator already initialised");
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  HIPCHK(c, hipSetDevice(c->cfg.device_ordinal));
+  ncclComm_t comm;
+  NCCLCHK(c, ncclCommInitRank(&comm, c->world, u, c->rank));
+  c->nccl_comm = comm;
+  return ALEPPO_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+extern "C" int aleppo_profile_enable(aleppo_ctx *c, int on) {
+  CHECK_CTX(c);
+  c->prof_on = on != 0;
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_profile_reset(aleppo_ctx *c) {
+  CHECK_CTX(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto &p : c->prof)
+    p.used = 0;
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_profile_read(aleppo_ctx *c, int cls, double *avg_ms, int64_t *launches) {
+  CHECK_CTX(c);
+  if (cls < 0 || cls >= ALEPPO_K_COUNT || !avg_ms || !launches)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "profile_read: bad argument");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ProfClass &p = c->prof[cls];
+  double tot = 0;
+  for (size_t i = 0; i < p.used; ++i) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+    tot += ms;
+  }
+  *launches = (int64_t)p.used;
+  *avg_ms = p.used ? tot / (double)p.used : 0.0;
+  return ALEPPO_OK;
+}
+
+// ------------------------------------------------------------------ stateless operators
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p)
+      hipFree(p);
+  }
+  hipError_t up(const void *src, size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e == hipSuccess && src)
+      e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    else if (e == hipSuccess)
+      e = hipMemset(p, 0, bytes ? bytes : 16);
+    return e;
+  }
+  template <class T> T *as() { return static_cast<T *>(p); }
+};
+} // namespace
+#define OPCHK(x)                                                                                                       \
+  do {                                                                                                                 \
+    hipError_t e_ = (x);                                                                                               \
+    if (e_ != hipSuccess)                                                                                              \
+      return set_err(nullptr, ALEPPO_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                         \
+  } while (0)
+
+extern "C" int aleppo_gae(int dev, float *advantages, const float *rewards, const float *values,
+                          const float *next_values, const uint8_t *terminals, const uint8_t *truncations,
+                          const uint8_t *episode_starts, int64_t E, int64_t T, float gamma, float lambda) {
+  if (!advantages || !rewards || !values || !next_values || !terminals || !truncations || !episode_starts)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT,
+                   "All input tensors must be 2D except next_values which must be 1D."); // gae.cc:8-13
+  if (E <= 0 || T <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "Input tensors must have compatible dimensions."); // :14-21
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  const size_t n = (size_t)E * T;
+  DevBuf a, r, v, nv, te, tr, st, er;
+  OPCHK(a.up(nullptr, n * 4));
+  OPCHK(r.up(rewards, n * 4));
+  OPCHK(v.up(values, n * 4));
+  OPCHK(nv.up(next_values, (size_t)E * 4));
+  OPCHK(te.up(terminals, n));
+  OPCHK(tr.up(truncations, n));
+  OPCHK(st.up(episode_starts, n));
+  OPCHK(er.up(nullptr, 16));
+  launch_gae_op(nullptr, a.as<float>(), r.as<float>(), v.as<float>(), nv.as<float>(), te.as<uint8_t>(),
+                tr.as<uint8_t>(), st.as<uint8_t>(), er.as<int>(), (int)E, (int)T, gamma, lambda);
+  int err = 0;
+  OPCHK(hipMemcpy(&err, er.p, 4, hipMemcpyDeviceToHost));
+  if (err)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT,
+                   "Episode starts, terminals, and truncations must be mutually exclusive."); // gae.cc:49-53
+  OPCHK(hipMemcpy(advantages, a.p, n * 4, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+
+extern "C" int aleppo_vision_resize_area(int dev, const float *images, float *out, int64_t n) {
+  if (!images || !out || n <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  DevBuf i, o;
+  OPCHK(i.up(images, (size_t)n * RAW_H * RAW_W * 4));
+  OPCHK(o.up(nullptr, (size_t)n * FRAME_PIX * 4));
+  launch_area_resize(nullptr, i.as<float>(), o.as<float>(), n);
+  OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX * 4, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_vision_rgb_to_gray(int dev, const float *images, float *out, int64_t n) {
+  if (!images || !out || n <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  DevBuf i, o;
+  OPCHK(i.up(images, (size_t)n * 3 * FRAME_PIX * 4));
+  OPCHK(o.up(nullptr, (size_t)n * FRAME_PIX * 4));
+  launch_rgb_to_gray(nullptr, i.as<float>(), o.as<float>(), n);
+  OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX * 4, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_preprocess(int dev, const uint8_t *raw_pairs, const uint8_t *lut256, uint8_t *out, int64_t n) {
+  if (!raw_pairs || !out || n <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  DevBuf i, l, o;
+  OPCHK(i.up(raw_pairs, (size_t)n * 2 * RAW_H * RAW_W));
+  if (lut256)
+    OPCHK(l.up(lut256, 256));
+  OPCHK(o.up(nullptr, (size_t)n * FRAME_PIX));
+  launch_preprocess(nullptr, i.as<uint8_t>(), lut256 ? l.as<uint8_t>() : nullptr, o.as<uint8_t>(), n);
+  OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_update_observations(int dev, uint8_t *observations, const uint8_t *frames,
+                                          const uint8_t *episode_start, int64_t E) {
+  if (!observations || !frames || !episode_start || E <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  DevBuf o, f, s;
+  OPCHK(o.up(observations, (size_t)E * 4 * FRAME_PIX));
+  OPCHK(f.up(frames, (size_t)E * FRAME_PIX));
+  OPCHK(s.up(episode_start, (size_t)E));
+  launch_update_obs_nchw(nullptr, o.as<uint8_t>(), f.as<uint8_t>(), s.as<uint8_t>(), E);
+  OPCHK(hipMemcpy(observations, o.p, (size_t)E * 4 * FRAME_PIX, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_ppo_loss(int dev, const float *logits, const float *old_lp, const int64_t *actions,
+                               const float *advantages, const float *values, const float *returns,
+                               const uint8_t *masks, int64_t B, int64_t A, float clip, float c_v, float c_e,
+                               float *loss, float *clipped, float *value_losses, float *entropies, float *total_losses,
+                               float *ratio, float *dlogits, float *dvalues) {
+  if (!logits || !old_lp || !actions || !advantages || !values || !returns || !masks || B <= 0 || A <= 0 ||
+      A > MAX_ACTIONS)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
+  for (int64_t i = 0; i < B; ++i)
+    if (actions[i] < 0 || actions[i] >= A)
+      return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "action index out of range");
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  DevBuf z, ol, ac, ad, va, re, ma, o[8];
+  OPCHK(z.up(logits, (size_t)B * A * 4));
+  OPCHK(ol.up(old_lp, (size_t)B * A * 4));
+  OPCHK(ac.up(actions, (size_t)B * 8));
+  OPCHK(ad.up(advantages, (size_t)B * 4));
+  OPCHK(va.up(values, (size_t)B * 4));
+  OPCHK(re.up(returns, (size_t)B * 4));
+  OPCHK(ma.up(masks, (size_t)B));
+  const size_t osz[8] = {4, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4,
+                         (size_t)B * A * 4, (size_t)B * 4};
+  for (int k = 0; k < 8; ++k)
+    OPCHK(o[k].up(nullptr, osz[k]));
+  launch_ppo_loss_op(nullptr, z.as<float>(), ol.as<float>(), ac.as<int64_t>(), ad.as<float>(), va.as<float>(),
+                     re.as<float>(), ma.as<uint8_t>(), B, (int)A, Hyper{clip, c_v, c_e, 0.f}, o[0].as<float>(),
+                     o[1].as<float>(), o[2].as<float>(), o[3].as<float>(), o[4].as<float>(), o[5].as<float>(),
+                     o[6].as<float>(), o[7].as<float>());
+  float *hd[8] = {loss, clipped, value_losses, entropies, total_losses, ratio, dlogits, dvalues};
+  for (int k = 0; k < 8; ++k)
+    if (hd[k])
+      OPCHK(hipMemcpy(hd[k], o[k].p, osz[k], hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_sample(int dev, const float *probs, const float *q, int64_t *actions, int64_t E, int64_t A) {
+  if (!probs || !q || !actions || E <= 0 || A <= 0)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
+  int rc = select_device(dev);
+  if (rc)
+    return rc;
+  DevBuf p, qq, a;
+  OPCHK(p.up(probs, (size_t)E * A * 4));
+  OPCHK(qq.up(q, (size_t)E * A * 4));
+  OPCHK(a.up(nullptr, (size_t)E * 8));
+  launch_sample_op(nullptr, p.as<float>(), qq.as<float>(), a.as<int64_t>(), E, (int)A);
+  OPCHK(hipMemcpy(actions, a.p, (size_t)E * 8, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}

@@ -1,0 +1,204 @@
+// common.hpp - internal context, HBM layout and launcher declarations of libaleppo.so.
+// Public boundary: include/aleppo.h.  Layout rationale: DESIGN.md.
+#pragma once
+#include "../../include/aleppo.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace aleppo {
+
+constexpr int FRAME_PIX = 84 * 84;          // 7056 packed pixels per stack (one u32 = 4 frames of one pixel)
+constexpr int RAW_H = 210, RAW_W = 160;
+constexpr int A1_PIX = 400, A1_C = 32;      // conv1 out 20x20x32 (NHWC)
+constexpr int A2_PIX = 81, A2_C = 64;       // conv2 out 9x9x64
+constexpr int A3_PIX = 49, A3_C = 64;       // conv3 out 7x7x64
+constexpr int FC_IN = 3136;
+constexpr int MAX_ACTIONS = 18;
+// split-K slice caps of the wgrad slabs (gemm_launch.hip) and of the head kernel's partial slabs
+constexpr int MAXS_C1 = 256, MAXS_C2 = 128, MAXS_C3 = 64, MAXS_FC = 4, MAXS_HEAD = 256;
+
+// ---- internal flat parameter layout (fp32 master, Adam moments, gradient share it) ----
+// order chosen so that what backward finishes FIRST is at the FRONT: bucket 0 = heads + fc can be
+// all-reduced while the conv backward still runs.  Every tensor starts 64-float aligned;
+// pads are zero and stay zero under Adam.
+enum ParamId { P_WH = 0, P_BH, P_WFC, P_BFC, P_W3, P_B3, P_W2, P_B2, P_W1, P_B1, P_COUNT };
+struct ParamLayout {
+  size_t off[P_COUNT + 1]; // off[P_COUNT] = total (padded)
+  size_t size[P_COUNT];
+  size_t bucket0_end;      // = off[P_W3]
+  int H, A;
+  void init(int H_, int A_);
+  size_t total() const { return off[P_COUNT]; }
+  size_t reference_count() const; // libtorch parameters() element count
+};
+// reference (libtorch parameters() order, NCHW) <-> internal (NHWC-k order) permutation, on the host
+void params_to_internal(const ParamLayout &L, const float *ref, float *internal);
+void params_to_reference(const ParamLayout &L, const float *internal, float *ref);
+
+// sample n of a batch lives in obs slot  (n / TP) * s1 + (n % TP) * s0 + base   (units: u32 pixels)
+struct SampleMap {
+  int TP;
+  long s1, s0, base;
+  int n0; // first sample of this launch (minibatch offset)
+};
+
+struct ProfClass {
+  std::vector<hipEvent_t> start, stop;
+  size_t used = 0;
+};
+
+struct Hyper {
+  float clip, c_v, c_e, max_norm;
+};
+
+struct Ctx {
+  aleppo_config cfg{};
+  int E = 0, T = 0, A = 0, H = 0, prec = 0, world = 1, rank = 0;
+  long N = 0;          // E*T samples per rollout on this rank
+  long maxB = 0;       // activation capacity in samples
+  long batch_n = 0;    // samples currently in the training arrays
+  ParamLayout L;
+  std::string err;
+  hipStream_t stream = nullptr, comm_stream = nullptr;
+  hipEvent_t ev_bucket0 = nullptr, ev_comm0 = nullptr, ev_comm1 = nullptr, ev_tmp = nullptr;
+  void *nccl_comm = nullptr;
+
+  // ---- rollout storage (time-major scalars, env-major packed observation slots) ----
+  uint32_t *obs = nullptr;     // [E][T+1][7056] packed stacks; slot T = bootstrap observation
+  uint8_t *step_rec = nullptr; // [T] records of { float r[E]; u8 term[E]; u8 trunc[E]; u8 start[E] }
+  size_t step_rec_bytes = 0;
+  float *values_tm = nullptr;  // [T+1][E]
+  float *logits_tm = nullptr;  // [T][E][A]
+  int *actions_tm = nullptr;   // [T][E]
+  uint8_t *lut = nullptr;      // [256]
+  uint8_t *d_start = nullptr;  // [E] episode-start flags of the slot being ingested
+  uint8_t *d_frames = nullptr; // staging for host frames (max(E*2*210*160))
+  float *d_noise = nullptr;    // [E][A]
+  int *d_err = nullptr;        // device error word (flag overlap)
+  // pinned host staging
+  int64_t *h_actions = nullptr; // [E]
+  uint8_t *h_step = nullptr;    // one step record
+  uint8_t *h_frames = nullptr;
+  float *h_noise = nullptr;
+  int *h_err = nullptr;
+  int t = 0;              // next slot to fill
+  bool need_carry = false; // copy slot T -> slot 0 before the next rollout's first act
+  uint64_t rng_counter = 0;
+  // ---- training arrays, env-major n = e*T + t ----
+  float *adv_n = nullptr, *ret_n = nullptr, *oldlp_n = nullptr; // [N], [N], [N][A]
+  int *act_n = nullptr;
+  uint8_t *mask_n = nullptr;
+  float *mask_counts = nullptr; // [M_max] global unmasked count per minibatch
+  // ---- network state ----
+  float *P = nullptr, *G = nullptr, *Gs = nullptr, *M1 = nullptr, *M2 = nullptr; // fp32, internal layout (Gs: clipped G)
+  void *Pc = nullptr;   // compute copy of P in T (same layout); == P for fp32
+  void *W2d = nullptr, *W3d = nullptr, *WfcT = nullptr; // dgrad-transposed copies in T
+  int64_t adam_step = 0;
+  // ---- activations (T unless noted) ----
+  void *a1 = nullptr, *a2 = nullptr, *a3 = nullptr; // [maxB][400][32], [maxB][81][64], [maxB][49][64]
+  float *h = nullptr;                               // [maxB][H] fp32
+  void *dh = nullptr;                               // [maxB][H] T
+  void *dz3 = nullptr, *dz2 = nullptr, *dz1 = nullptr;
+  float *logits_b = nullptr, *values_b = nullptr;   // [maxB][A], [maxB] (forward-only API / debug)
+  // ---- gradient slabs ----
+  float *slab = nullptr;
+  size_t slab_floats = 0;
+  size_t slab_off[11] = {0}; // W1 b1 W2 b2 W3 b3 Wfc bfc Wh bh
+  float *adv_stats = nullptr;
+  float *sumsq_part = nullptr; // [1024]
+  // ---- per-sample train metrics [mi][B] x 5, and reduced [mi][8] ----
+  float *metric_ps = nullptr;
+  size_t metric_cap = 0; // floats per field
+  size_t metric_red_cap = 0;
+  float *metric_red = nullptr, *h_metric_red = nullptr;
+  float *grad_norms = nullptr; // [mi]
+  int last_epochs = 0, last_M = 0;
+  long last_B = 0;
+  // ---- profiling ----
+  bool prof_on = false;
+  ProfClass prof[ALEPPO_K_COUNT];
+};
+
+int set_err(Ctx *c, int code, const std::string &msg);
+#define HIPCHK(c, x)                                                                                                   \
+  do {                                                                                                                 \
+    hipError_t e_ = (x);                                                                                               \
+    if (e_ != hipSuccess)                                                                                              \
+      return set_err((c), ALEPPO_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                           \
+  } while (0)
+
+// ------------------------------------------------------------------ kernel launchers (kernels.hip)
+void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
+                   uint32_t *obs, int E, int slots, int t_src, int t_dst);
+void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, int dst);
+void launch_infer_head(hipStream_t s, const float *h, const float *Wh, const float *bh, const float *noise,
+                       uint64_t seed, uint64_t counter, float *logits_t, float *values_t, int *actions_t,
+                       int64_t *pinned, int E, int H, int A);
+void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
+                const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
+                int *err, int E, int T, int A, float gamma, float lambda);
+void launch_adv_norm(hipStream_t s, float *adv_n, const uint8_t *mask_n, float *stats, long n, int phase);
+void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long B, int M);
+void launch_head_train(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
+                       const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
+                       const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
+                       float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
+                       long B, int H, int A, float *logits_out, float *values_out);
+struct ReduceSeg {
+  const float *slab;
+  int S;
+  long n;
+  long dst;
+};
+void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *G);
+void launch_sumsq(hipStream_t s, const float *G, long n, float *partials, int nblk);
+void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
+                 int prec, long n, const float *partials, int nblk, float max_norm, float step_size, float bc2_sqrt,
+                 float beta1, float beta2, float eps, float *grad_norm_out);
+void launch_pack_dgrad(hipStream_t s, const float *P, const ParamLayout &L, void *W2d, void *W3d, void *WfcT,
+                       int prec);
+void launch_cast_params(hipStream_t s, const float *P, void *Pc, long n);
+void launch_metrics_reduce(hipStream_t s, const float *ps, size_t field_stride, const uint8_t *mask_n, long B, int M,
+                           int epochs, float *out);
+void launch_obs_unpack(hipStream_t s, const uint32_t *obs, uint8_t *out, long nsamp, SampleMap map);
+void launch_obs_pack(hipStream_t s, const uint8_t *in, uint32_t *obs, long nsamp, SampleMap map);
+void launch_transpose_tm_pitched(hipStream_t s, const void *src_tm, size_t pitch, void *dst_em, int E, int T, int inner,
+                                 int elem);
+void launch_heads_fwd(hipStream_t s, const float *h, const float *Wh, const float *bh, float *logits, float *values,
+                      long n, int H, int A);
+void launch_logsoftmax_rows(hipStream_t s, const float *in, float *out, long rows, int A);
+// stateless operators
+void launch_gae_op(hipStream_t s, float *adv, const float *r, const float *v, const float *nv, const uint8_t *term,
+                   const uint8_t *trunc, const uint8_t *start, int *err, int E, int T, float gamma, float lambda);
+void launch_area_resize(hipStream_t s, const float *in, float *out, long n);
+void launch_rgb_to_gray(hipStream_t s, const float *in, float *out, long n);
+void launch_preprocess(hipStream_t s, const uint8_t *raw, const uint8_t *lut, uint8_t *out, long n);
+void launch_update_obs_nchw(hipStream_t s, uint8_t *obs, const uint8_t *frames, const uint8_t *start, long E);
+void launch_ppo_loss_op(hipStream_t s, const float *logits, const float *oldlp, const int64_t *actions,
+                        const float *adv, const float *values, const float *ret, const uint8_t *mask, long B, int A,
+                        Hyper hp, float *loss, float *clipped, float *value_losses, float *entropies,
+                        float *total_losses, float *ratio, float *dlogits, float *dvalues);
+void launch_sample_op(hipStream_t s, const float *probs, const float *q, int64_t *actions, long E, int A);
+
+// ------------------------------------------------------------------ GEMM launchers (gemm_launch.hip)
+// prec selects T (ALEPPO_FP32 / ALEPPO_BF16); all pointers are device pointers of the matching type.
+void conv1_fwd(hipStream_t s, int prec, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
+               long ns);
+void conv2_fwd(hipStream_t s, int prec, const void *a1, const void *W2, const float *b2, void *a2, long ns);
+void conv3_fwd(hipStream_t s, int prec, const void *a2, const void *W3, const float *b3, void *a3, long ns);
+void fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H);
+void fc_dgrad(hipStream_t s, int prec, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H);
+void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns);
+void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns);
+// wgrads write split-K slabs; return the number of slices S used (slab holds S*[M*N] then bias S*[M])
+int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *slab_w, float *slab_b, long ns, int H);
+int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float *slab_w, float *slab_b, long ns);
+int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *slab_w, float *slab_b, long ns);
+int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *slab_w,
+                float *slab_b, long ns);
+
+} // namespace aleppo
+
+struct aleppo_ctx : aleppo::Ctx {};

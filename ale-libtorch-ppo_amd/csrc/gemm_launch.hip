@@ -1,0 +1,236 @@
+// gemm_launch.hip - instantiations + launch geometry of the conv / linear stack kernels (gemm.hpp).
+// Layer shapes follow NetworkImpl (reference src/bin/train.cc:232-244); activations are NHWC,
+// weights [oc][(kh,kw,c)].  No vendor BLAS / MIOpen on this path.
+#include "common.hpp"
+#include "gemm.hpp"
+
+namespace aleppo {
+
+static inline dim3 grid2(long M, int BM, long N, int BN, int Z = 1) {
+  return dim3((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), (unsigned)Z);
+}
+
+// ------------------------------------------------------------------ forward
+template <class T>
+static void conv1_fwd_t(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
+                        long ns) {
+  // A: packed u8 stack [84][84][4] per sample, 8x8 s4 window -> k = (kh, kw*4+c), 32 contiguous bytes per kh
+  using AL = ConvGatherLoader<T, uint8_t, 400, 20, 4, 84, 4, 8>;
+  using BL = DenseLoader<T>;
+  using EP = EpiBiasAct<T, true>;
+  const long M = ns * 400;
+  typename AL::P ap{reinterpret_cast<const uint8_t *>(obs), map.TP, map.s1 * 4, map.s0 * 4, map.base * 4, map.n0};
+  typename BL::P bp{static_cast<const T *>(W1), 256, 0};
+  typename EP::P ep{static_cast<T *>(a1), b1, 32, 1.0f / 255.0f}; // x/255 folded into the epilogue (train.cc:258-259)
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 32, 4, 1>), grid2(M, 128, 32, 32), dim3(256), 0, s, ap, bp,
+                     ep, (int)M, 32, 256);
+}
+template <class T>
+static void conv2_fwd_t(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
+  using AL = ConvGatherLoader<T, T, 81, 9, 2, 20, 32, 4>;
+  using BL = DenseLoader<T>;
+  using EP = EpiBiasAct<T, true>;
+  const long M = ns * 81;
+  typename AL::P ap{static_cast<const T *>(a1), 1, 400 * 32, 0, 0, 0};
+  typename BL::P bp{static_cast<const T *>(W2), 512, 0};
+  typename EP::P ep{static_cast<T *>(a2), b2, 64, 1.0f};
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(M, 128, 64, 64), dim3(256), 0, s, ap, bp,
+                     ep, (int)M, 64, 512);
+}
+template <class T>
+static void conv3_fwd_t(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
+  using AL = ConvGatherLoader<T, T, 49, 7, 1, 9, 64, 3>;
+  using BL = DenseLoader<T>;
+  using EP = EpiBiasAct<T, true>;
+  const long M = ns * 49;
+  typename AL::P ap{static_cast<const T *>(a2), 1, 81 * 64, 0, 0, 0};
+  typename BL::P bp{static_cast<const T *>(W3), 576, 0};
+  typename EP::P ep{static_cast<T *>(a3), b3, 64, 1.0f};
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(M, 128, 64, 64), dim3(256), 0, s, ap, bp,
+                     ep, (int)M, 64, 576);
+}
+template <class T>
+static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H) {
+  using AL = DenseLoader<T>;
+  using BL = DenseLoader<T>;
+  using EP = EpiBiasAct<float, false>; // NO relu after the 3136->H linear
+  typename AL::P ap{static_cast<const T *>(a3), FC_IN, 0};
+  typename BL::P bp{static_cast<const T *>(Wfc), FC_IN, 0};
+  typename EP::P ep{h, bfc, H, 1.0f};
+  if (ns <= 256) // acting batch: smaller M tile so more workgroups share the 3136-deep reduction
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 32, 32, 2, 2>), grid2(ns, 32, H, 32), dim3(256), 0, s, ap, bp,
+                       ep, (int)ns, H, FC_IN);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(ns, 128, H, 64), dim3(256), 0, s, ap,
+                       bp, ep, (int)ns, H, FC_IN);
+}
+
+// ------------------------------------------------------------------ dgrad
+template <class T>
+static void fc_dgrad_t(hipStream_t s, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H) {
+  using AL = DenseLoader<T>;
+  using BL = DenseLoader<T>;
+  using EP = EpiReluMask<T, 0>;
+  typename AL::P ap{static_cast<const T *>(dh), H, 0};
+  typename BL::P bp{static_cast<const T *>(WfcT), H, 0};
+  typename EP::P ep{static_cast<T *>(dz3), static_cast<const T *>(a3), FC_IN, 0};
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(ns, 128, FC_IN, 64), dim3(256), 0, s, ap,
+                     bp, ep, (int)ns, FC_IN, H);
+}
+template <class T>
+static void conv3_dgrad_t(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
+  using AL = DgradGatherLoader<T, 9, 9, 7, 7, 64, 3>;
+  using BL = DenseLoader<T>;
+  using EP = EpiReluMask<T, 0>;
+  const long M = ns * 81;
+  typename AL::P ap{static_cast<const T *>(dz3)};
+  typename BL::P bp{static_cast<const T *>(W3d), 576, 0};
+  typename EP::P ep{static_cast<T *>(dz2), static_cast<const T *>(a2), 64, 0};
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(M, 128, 64, 64), dim3(256), 0, s, ap, bp,
+                     ep, (int)M, 64, 576);
+}
+template <class T>
+static void conv2_dgrad_t(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
+  // one grid.z slice per input-pixel parity class (py,px): only the 2x2 taps with kh=py (mod 2), kw=px (mod 2)
+  using AL = DgradGatherLoader<T, 10, 10, 9, 9, 64, 2>;
+  using BL = DenseLoader<T>;
+  using EP = EpiReluMask<T, 1>;
+  const long M = ns * 100;
+  typename AL::P ap{static_cast<const T *>(dz2)};
+  typename BL::P bp{static_cast<const T *>(W2d), 256, 32 * 256};
+  typename EP::P ep{static_cast<T *>(dz1), static_cast<const T *>(a1), 32, 0};
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 32, 4, 1>), grid2(M, 128, 32, 32, 4), dim3(256), 0, s, ap,
+                     bp, ep, (int)M, 32, 256);
+}
+
+// ------------------------------------------------------------------ wgrad (split-K slabs)
+static inline int pick_slices(long Ktot, int KP, int tiles_mn, int maxS) {
+  long S = 512 / tiles_mn;
+  const long cap = Ktot / (2L * KP);
+  if (S > cap)
+    S = cap;
+  if (S > maxS)
+    S = maxS;
+  if (S < 1)
+    S = 1;
+  return (int)S;
+}
+static inline int chunk_for(long Ktot, int S, int KP) {
+  long c = (Ktot + S - 1) / S;
+  c = (c + KP - 1) / KP * KP;
+  return (int)c;
+}
+
+template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const void *a3, float *sw, float *sb, long ns, int H) {
+  using AL = DenseLoader<T>;
+  using BL = DenseLoader<T>;
+  constexpr int KP = Atom<T>::KT;
+  const dim3 g = grid2(H, 64, FC_IN, 128);
+  const int S = pick_slices(ns, KP, g.x * g.y, MAXS_FC);
+  const int kc = chunk_for(ns, S, KP);
+  typename AL::P ap{static_cast<const T *>(dh), H, 0};
+  typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
+  hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
+                     sb, H, FC_IN, (int)ns, kc);
+  return S;
+}
+template <class T> static int conv3_wgrad_t(hipStream_t s, const void *dz3, const void *a2, float *sw, float *sb, long ns) {
+  using AL = DenseLoader<T>;
+  using BL = ConvGatherLoader<T, T, 49, 7, 1, 9, 64, 3>;
+  constexpr int KP = Atom<T>::KT;
+  const long K = ns * 49;
+  const dim3 g = grid2(64, 64, 576, 64);
+  const int S = pick_slices(K, KP, g.x * g.y, MAXS_C3);
+  const int kc = chunk_for(K, S, KP);
+  typename AL::P ap{static_cast<const T *>(dz3), 64, 0};
+  typename BL::P bp{static_cast<const T *>(a2), 1, 81 * 64, 0, 0, 0};
+  hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
+                     sb, 64, 576, (int)K, kc);
+  return S;
+}
+template <class T> static int conv2_wgrad_t(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns) {
+  using AL = DenseLoader<T>;
+  using BL = ConvGatherLoader<T, T, 81, 9, 2, 20, 32, 4>;
+  constexpr int KP = Atom<T>::KT;
+  const long K = ns * 81;
+  const dim3 g = grid2(64, 64, 512, 128);
+  const int S = pick_slices(K, KP, g.x * g.y, MAXS_C2);
+  const int kc = chunk_for(K, S, KP);
+  typename AL::P ap{static_cast<const T *>(dz2), 64, 0};
+  typename BL::P bp{static_cast<const T *>(a1), 1, 400 * 32, 0, 0, 0};
+  hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
+                     sb, 64, 512, (int)K, kc);
+  return S;
+}
+template <class T>
+static int conv1_wgrad_t(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
+                         long ns) {
+  using AL = DenseLoader<T>;
+  using BL = ConvGatherLoader<T, uint8_t, 400, 20, 4, 84, 4, 8>;
+  constexpr int KP = Atom<T>::KT;
+  const long K = ns * 400;
+  const dim3 g = grid2(32, 32, 256, 128);
+  const int S = pick_slices(K, KP, g.x * g.y, MAXS_C1);
+  const int kc = chunk_for(K, S, KP);
+  typename AL::P ap{static_cast<const T *>(dz1), 32, 0};
+  typename BL::P bp{reinterpret_cast<const uint8_t *>(obs), map.TP, map.s1 * 4, map.s0 * 4, map.base * 4, map.n0};
+  hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 32, 128, 1, 4, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
+                     sb, 32, 256, (int)K, kc);
+  return S;
+}
+
+// ------------------------------------------------------------------ precision dispatch
+#define DISPATCH(prec, call_f32, call_bf16)                                                                            \
+  do {                                                                                                                 \
+    if ((prec) == ALEPPO_BF16) {                                                                                       \
+      call_bf16;                                                                                                       \
+    } else {                                                                                                           \
+      call_f32;                                                                                                        \
+    }                                                                                                                  \
+  } while (0)
+
+void conv1_fwd(hipStream_t s, int prec, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
+               long ns) {
+  DISPATCH(prec, conv1_fwd_t<float>(s, obs, map, W1, b1, a1, ns), conv1_fwd_t<bf16>(s, obs, map, W1, b1, a1, ns));
+}
+void conv2_fwd(hipStream_t s, int prec, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
+  DISPATCH(prec, conv2_fwd_t<float>(s, a1, W2, b2, a2, ns), conv2_fwd_t<bf16>(s, a1, W2, b2, a2, ns));
+}
+void conv3_fwd(hipStream_t s, int prec, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
+  DISPATCH(prec, conv3_fwd_t<float>(s, a2, W3, b3, a3, ns), conv3_fwd_t<bf16>(s, a2, W3, b3, a3, ns));
+}
+void fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H) {
+  DISPATCH(prec, fc_fwd_t<float>(s, a3, Wfc, bfc, h, ns, H), fc_fwd_t<bf16>(s, a3, Wfc, bfc, h, ns, H));
+}
+void fc_dgrad(hipStream_t s, int prec, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H) {
+  DISPATCH(prec, fc_dgrad_t<float>(s, dh, WfcT, a3, dz3, ns, H), fc_dgrad_t<bf16>(s, dh, WfcT, a3, dz3, ns, H));
+}
+void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
+  DISPATCH(prec, conv3_dgrad_t<float>(s, dz3, W3d, a2, dz2, ns), conv3_dgrad_t<bf16>(s, dz3, W3d, a2, dz2, ns));
+}
+void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
+  DISPATCH(prec, conv2_dgrad_t<float>(s, dz2, W2d, a1, dz1, ns), conv2_dgrad_t<bf16>(s, dz2, W2d, a1, dz1, ns));
+}
+int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *sw, float *sb, long ns, int H) {
+  if (prec == ALEPPO_BF16)
+    return fc_wgrad_t<bf16>(s, dh, a3, sw, sb, ns, H);
+  return fc_wgrad_t<float>(s, dh, a3, sw, sb, ns, H);
+}
+int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float *sw, float *sb, long ns) {
+  if (prec == ALEPPO_BF16)
+    return conv3_wgrad_t<bf16>(s, dz3, a2, sw, sb, ns);
+  return conv3_wgrad_t<float>(s, dz3, a2, sw, sb, ns);
+}
+int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *sw, float *sb, long ns) {
+  if (prec == ALEPPO_BF16)
+    return conv2_wgrad_t<bf16>(s, dz2, a1, sw, sb, ns);
+  return conv2_wgrad_t<float>(s, dz2, a1, sw, sb, ns);
+}
+int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
+                long ns) {
+  if (prec == ALEPPO_BF16)
+    return conv1_wgrad_t<bf16>(s, dz1, obs, map, sw, sb, ns);
+  return conv1_wgrad_t<float>(s, dz1, obs, map, sw, sb, ns);
+}
+
+} // namespace aleppo

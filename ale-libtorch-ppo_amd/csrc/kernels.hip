@@ -1,0 +1,989 @@
+// kernels.hip - HBM-bound / latency-bound kernels of the PPO-over-ALE hot path for gfx950:
+// frame ingest (LUT + area resize + 2-frame max + 4-frame stack + rollout-slot write), action head +
+// categorical sampling, reward clamp + GAE + returns + old log-probs, PPO loss forward/backward fused
+// with the head linear layers, split-K slab reduction, global-norm clip + Adam, and the layout
+// conversions used only at the C-ABI boundary.  Each kernel cites the reference code it replaces.
+#include "common.hpp"
+#include "gemm.hpp" // bf16 / vector typedefs
+
+namespace aleppo {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v += __shfl_xor(v, o, 64);
+  return v;
+}
+// deterministic block reduction (256 threads): wave shuffles, then wave 0 sums the 4 partials in order
+__device__ __forceinline__ float block_sum_256(float v, float *s4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0)
+    s4[wave] = v;
+  __syncthreads();
+  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+// ================================================================================================
+// Frame ingest.  Replaces, per env-step: gray LUT (environment.cc:48-55) + resize (vision.cc:86-95 on
+// the env threads; here the area spec of vision.cc:8-32) + 2-frame max (max_and_skip.cc:33-42) +
+// Rollout::update_observations (rollout.cc:184-196) + Buffer::add's observation copy (buffer.cc:47).
+// The 4-frame stack of one pixel is ONE u32 (byte 0 = newest frame, Q11), so "shift + insert" is
+// (old << 8) | new and "broadcast on episode start" is new * 0x01010101.  The stack for slot t+1
+// is written straight into the rollout buffer; slot t is never copied again.
+// grid (7 bands of 12 output rows, E), 256 threads; a band needs exactly 30 raw rows per frame.
+// ================================================================================================
+template <bool RAW>
+__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ lut,
+                                                      const uint8_t *__restrict__ start, uint32_t *obs, int slots,
+                                                      int t_src, int t_dst) {
+  const int e = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t sraw[2 * 30 * RAW_W];
+  __shared__ uint8_t slut[256];
+  if (RAW) {
+    for (int v = tid; v < 600; v += 256) { // 2 frames x 30 rows x 10 16-byte vectors, coalesced
+      const int f = v / 300, r = v - f * 300;
+      const u32x4 *src =
+          reinterpret_cast<const u32x4 *>(frames + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)band * 30 * RAW_W);
+      reinterpret_cast<u32x4 *>(sraw)[v] = src[r];
+    }
+    slut[tid] = lut[tid];
+    __syncthreads();
+  }
+  const bool st = start[e] != 0;
+  const uint32_t *src = obs + ((size_t)e * slots + t_src) * FRAME_PIX;
+  uint32_t *dst = obs + ((size_t)e * slots + t_dst) * FRAME_PIX;
+  for (int pix = tid; pix < 12 * 84; pix += 256) {
+    const int il = pix / 84, j = pix - il * 84, i = band * 12 + il;
+    uint32_t v;
+    if (RAW) {
+      const int y0 = (i * RAW_H) / 84 - band * 30, y1 = ((i + 1) * RAW_H + 83) / 84 - band * 30;
+      const int x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84;
+      int best = 0;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        int s = 0;
+        for (int y = y0; y < y1; ++y)
+          for (int x = x0; x < x1; ++x)
+            s += slut[sraw[(f * 30 + y) * RAW_W + x]];
+        // adaptive-average (area) mean in f32 like interpolate(mode=area), round-half-even to u8
+        const int q = (int)rintf((float)s / (float)((y1 - y0) * (x1 - x0)));
+        best = max(best, q);
+      }
+      v = (uint32_t)min(best, 255);
+    } else {
+      v = frames[(size_t)e * FRAME_PIX + i * 84 + j];
+    }
+    const uint32_t old = src[i * 84 + j];
+    dst[i * 84 + j] = st ? v * 0x01010101u : ((old << 8) | v);
+  }
+}
+
+void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
+                   uint32_t *obs, int E, int slots, int t_src, int t_dst) {
+  if (raw)
+    hipLaunchKernelGGL(ingest_kernel<true>, dim3(7, E), dim3(256), 0, s, frames, lut, start, obs, slots, t_src, t_dst);
+  else
+    hipLaunchKernelGGL(ingest_kernel<false>, dim3(7, E), dim3(256), 0, s, frames, lut, start, obs, slots, t_src,
+                       t_dst);
+}
+
+__global__ void copy_slot_kernel(uint32_t *obs, int slots, int src, int dst) {
+  const int e = blockIdx.y;
+  const u32x4 *s = reinterpret_cast<const u32x4 *>(obs + ((size_t)e * slots + src) * FRAME_PIX);
+  u32x4 *d = reinterpret_cast<u32x4 *>(obs + ((size_t)e * slots + dst) * FRAME_PIX);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < FRAME_PIX / 4)
+    d[i] = s[i];
+}
+void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, int dst) {
+  hipLaunchKernelGGL(copy_slot_kernel, dim3((FRAME_PIX / 4 + 255) / 256, E), dim3(256), 0, s, obs, slots, src, dst);
+}
+
+// ================================================================================================
+// Action head + categorical sampling (action selector closure, train.cc:367-379): logits / value from
+// the hidden vector, softmax, multinomial(1, replacement) == argmax_k(p_k / q_k), q ~ Exp(1) (Q10),
+// first maximum wins.  One wave per environment.  Actions go to the rollout slot AND to pinned host
+// memory (replaces the per-env .item<int64_t>() of rollout.cc:312-313).
+// ================================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ h, const float *__restrict__ Wh,
+                                                          const float *__restrict__ bh, const float *__restrict__ noise,
+                                                          uint64_t seed, uint64_t counter, float *logits_t,
+                                                          float *values_t, int *actions_t, int64_t *pinned, int E, int H,
+                                                          int A) {
+  __shared__ float sz[4][MAX_ACTIONS + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 4 + wave;
+  if (e >= E)
+    return;
+  const float *hr = h + (size_t)e * H;
+  for (int a = 0; a <= A; ++a) {
+    float s = 0.f;
+    for (int j = lane; j < H; j += 64)
+      s += hr[j] * Wh[(size_t)a * H + j];
+    s = wave_sum(s);
+    if (lane == 0)
+      sz[wave][a] = s + bh[a];
+  }
+  if (lane == 0) {
+    const float *z = sz[wave];
+    float mx = z[0];
+    for (int k = 1; k < A; ++k)
+      mx = fmaxf(mx, z[k]);
+    float sum = 0.f;
+    for (int k = 0; k < A; ++k)
+      sum += expf(z[k] - mx);
+    int best = 0;
+    float bv = -1.f;
+    for (int k = 0; k < A; ++k) {
+      const float p = expf(z[k] - mx) / sum;
+      float q;
+      if (noise) {
+        q = noise[(size_t)e * A + k];
+      } else {
+        uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)e, (uint32_t)(k >> 2)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float u = ((float)(c[k & 3] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0,1)
+        q = -logf(u);
+      }
+      const float r = p / q;
+      if (r > bv) {
+        bv = r;
+        best = k;
+      }
+      logits_t[(size_t)e * A + k] = z[k];
+    }
+    values_t[e] = z[A];
+    actions_t[e] = best;
+    pinned[e] = best;
+  }
+}
+void launch_infer_head(hipStream_t s, const float *h, const float *Wh, const float *bh, const float *noise,
+                       uint64_t seed, uint64_t counter, float *logits_t, float *values_t, int *actions_t,
+                       int64_t *pinned, int E, int H, int A) {
+  hipLaunchKernelGGL(infer_head_kernel, dim3((E + 3) / 4), dim3(256), 0, s, h, Wh, bh, noise, seed, counter, logits_t,
+                     values_t, actions_t, pinned, E, H, A);
+}
+
+// ================================================================================================
+// Reward clamp + GAE + returns + masks + old log-probs in ONE pass: Buffer::get (buffer.cc:58-77),
+// ai::gae::gae (gae.cc:49-79) and prepare_batch's normalize_logits (train.cc:272-283).
+// Rollout scalars are time-major [T][E] so each wave reads 64 consecutive environments per slot
+// (coalesced); one thread owns one environment and scans t = T-1..0.  Outputs are the env-major
+// (n = e*T + t) training arrays the minibatch slices index (Q1, Q5).  The float op order of
+// gae.cc:61-66 is pinned with __f*_rn so no fma contraction changes the rounding.
+// ================================================================================================
+__device__ __forceinline__ float gae_step(float r, float v, float nv, float last, float gamma, float gl, bool st,
+                                          bool te, bool tr) {
+  const float boot = __fsub_rn(__fadd_rn(r, __fmul_rn(gamma, nv)), v); // (r + g*nv) - v
+  float a = __fadd_rn(boot, __fmul_rn(gl, last));                      // running,   gae.cc:61-63
+  if (st)
+    a = 0.f;                                                           // start,     gae.cc:68-69
+  if (te)
+    a = __fsub_rn(r, v);                                               // terminal,  gae.cc:64,70-71
+  if (tr)
+    a = boot;                                                          // truncated, gae.cc:65-66,72-73
+  return a;
+}
+
+__global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const float *__restrict__ values_tm,
+                                                  const float *__restrict__ logits_tm, const int *__restrict__ actions_tm,
+                                                  float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
+                                                  int *err, int E, int T, int A, float gamma, float lambda) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E)
+    return;
+  const float gl = __fmul_rn(gamma, lambda);
+  float last = 0.f, nv = values_tm[(size_t)T * E + e];
+  for (int t = T - 1; t >= 0; --t) {
+    float *rp = reinterpret_cast<float *>(rec + (size_t)t * rb);
+    const uint8_t *fl = rec + (size_t)t * rb + 4 * (size_t)E;
+    float r = rp[e];
+    r = fminf(fmaxf(r, -1.0f), 1.0f); // buffer.cc:67 clamp_, in place
+    rp[e] = r;
+    const bool te = fl[e] != 0, tr = fl[E + e] != 0, st = fl[2 * E + e] != 0;
+    if ((int)te + (int)tr + (int)st > 1)
+      *err = 1; // gae.cc:49-53
+    const float v = values_tm[(size_t)t * E + e];
+    const float a = gae_step(r, v, nv, last, gamma, gl, st, te, tr);
+    const size_t n = (size_t)e * T + t;
+    adv_n[n] = a;
+    ret_n[n] = __fadd_rn(a, v); // buffer.cc:70-71
+    mask_n[n] = st ? 0 : 1;     // buffer.cc:74
+    act_n[n] = actions_tm[(size_t)t * E + e];
+    const float *z = logits_tm + ((size_t)t * E + e) * A;
+    float mx = z[0];
+    for (int k = 1; k < A; ++k)
+      mx = fmaxf(mx, z[k]);
+    float s = 0.f;
+    for (int k = 0; k < A; ++k)
+      s += expf(z[k] - mx);
+    const float lse = mx + logf(s);
+    for (int k = 0; k < A; ++k)
+      oldlp_n[n * A + k] = z[k] - lse; // train.cc:279 normalize_logits
+    last = a;
+    nv = v;
+  }
+}
+void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
+                const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
+                int *err, int E, int T, int A, float gamma, float lambda) {
+  hipLaunchKernelGGL(gae_kernel, dim3((E + 63) / 64), dim3(64), 0, s, step_rec, rec_bytes, values_tm, logits_tm,
+                     actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n, err, E, T, A, gamma, lambda);
+}
+
+// stateless ai::gae::gae on env-major host-layout arrays (parity tests)
+__global__ void gae_op_kernel(float *adv, const float *r, const float *v, const float *nv0, const uint8_t *term,
+                              const uint8_t *trunc, const uint8_t *start, int *err, int E, int T, float gamma,
+                              float lambda) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E)
+    return;
+  const float gl = __fmul_rn(gamma, lambda);
+  float last = 0.f, nv = nv0[e];
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t k = (size_t)e * T + t;
+    const bool te = term[k] != 0, tr = trunc[k] != 0, st = start[k] != 0;
+    if ((int)te + (int)tr + (int)st > 1)
+      *err = 1;
+    const float a = gae_step(r[k], v[k], nv, last, gamma, gl, st, te, tr);
+    adv[k] = a;
+    last = a;
+    nv = v[k];
+  }
+}
+void launch_gae_op(hipStream_t s, float *adv, const float *r, const float *v, const float *nv, const uint8_t *term,
+                   const uint8_t *trunc, const uint8_t *start, int *err, int E, int T, float gamma, float lambda) {
+  hipLaunchKernelGGL(gae_op_kernel, dim3((E + 63) / 64), dim3(64), 0, s, adv, r, v, nv, term, trunc, start, err, E, T,
+                     gamma, lambda);
+}
+
+// optional advantage normalisation over unmasked samples (NOT in the reference, Q2; off by default).
+// phase 0: stats[0..2] += {sum, sumsq, count} (one block, deterministic); phase 1: apply.
+__global__ __launch_bounds__(256) void adv_norm_kernel(float *adv, const uint8_t *mask, float *stats, long n, int phase) {
+  __shared__ float s4[4];
+  if (phase == 0) {
+    float s = 0.f, q = 0.f, c = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256)
+      if (mask[i]) {
+        s += adv[i];
+        q += adv[i] * adv[i];
+        c += 1.f;
+      }
+    s = block_sum_256(s, s4);
+    q = block_sum_256(q, s4);
+    c = block_sum_256(c, s4);
+    if (threadIdx.x == 0) {
+      stats[0] = s;
+      stats[1] = q;
+      stats[2] = c;
+    }
+  } else {
+    const float c = stats[2], mean = stats[0] / c;
+    const float var = fmaxf((stats[1] - c * mean * mean) / fmaxf(c - 1.f, 1.f), 0.f);
+    const float inv = 1.0f / (sqrtf(var) + 1e-8f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+      adv[i] = (adv[i] - mean) * inv;
+  }
+}
+void launch_adv_norm(hipStream_t s, float *adv_n, const uint8_t *mask_n, float *stats, long n, int phase) {
+  hipLaunchKernelGGL(adv_norm_kernel, dim3(phase == 0 ? 1 : (unsigned)((n + 255) / 256)), dim3(256), 0, s, adv_n,
+                     mask_n, stats, n, phase);
+}
+
+// unmasked-sample count per minibatch (losses.cc:19 masks.sum()); block per minibatch
+__global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t *mask, float *counts, long B) {
+  __shared__ float s4[4];
+  const uint8_t *m = mask + (size_t)blockIdx.x * B;
+  float c = 0.f;
+  for (long i = threadIdx.x; i < B; i += 256)
+    c += m[i] ? 1.f : 0.f;
+  c = block_sum_256(c, s4);
+  if (threadIdx.x == 0)
+    counts[blockIdx.x] = c;
+}
+void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long B, int M) {
+  hipLaunchKernelGGL(mask_count_kernel, dim3(M), dim3(256), 0, s, mask_n, counts, B);
+}
+
+// ================================================================================================
+// PPO head, training.  Fuses: action/value linear layers (train.cc:245-253,262-263), normalize_logits
+// (losses.cc:45-47), losses::compute forward (losses.cc:4-26) with its closed-form backward (SURVEY
+// app. B: autograd's gradient of the masked-mean loss), the head dgrad (dh) and the head wgrad
+// partials.  One wave per sample row, 4 waves per workgroup, rows strided over the grid; every
+// workgroup writes ONE partial slab of head-weight gradients (summed later in fixed order).
+// 1/N_m uses the GLOBAL unmasked count so that an all-reduce SUM over ranks yields the mean (8e).
+// ================================================================================================
+template <class T, int AMAX>
+__global__ __launch_bounds__(256) void head_train_kernel(
+    const float *__restrict__ h, const float *__restrict__ Wh, const float *__restrict__ bh,
+    const int *__restrict__ act, const float *__restrict__ oldlp, const float *__restrict__ adv,
+    const float *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
+    T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
+    float *slab_b, long B, int H, int A, float *logits_out, float *values_out) {
+  constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
+  extern __shared__ float smem[];
+  float *sW = smem;                    // [(A+1)][H]
+  float *sAcc = smem + (size_t)A1 * H; // [(A+1)][H] cross-wave wgrad accumulator
+  float *sB = sAcc + (size_t)A1 * H;   // [4][A1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < (A + 1) * H; i += 256) {
+    sW[i] = Wh[i];
+    sAcc[i] = 0.f;
+  }
+  __syncthreads();
+  const float inv_nm = 1.0f / mask_count[0];
+  float gW[A1][HPL], gb[A1];
+#pragma unroll
+  for (int a = 0; a < A1; ++a) {
+    gb[a] = 0.f;
+#pragma unroll
+    for (int i = 0; i < HPL; ++i)
+      gW[a][i] = 0.f;
+  }
+  const long rows_per_blk = (B + gridDim.x - 1) / gridDim.x;
+  const long row0 = (long)blockIdx.x * rows_per_blk, row1 = min(B, row0 + rows_per_blk);
+  for (long row = row0 + wave; row < row1; row += 4) {
+    float hv[HPL];
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) {
+      const int j = lane + 64 * i;
+      hv[i] = j < H ? h[(size_t)row * H + j] : 0.f;
+    }
+    float z[A1];
+#pragma unroll
+    for (int a = 0; a < A1; ++a) {
+      float s = 0.f;
+      if (a <= A) {
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+          const int j = lane + 64 * i;
+          if (j < H)
+            s += hv[i] * sW[a * H + j];
+        }
+        s = wave_sum(s) + bh[a];
+      }
+      z[a] = s;
+    }
+    // every lane now holds logits z[0..A-1] and the value z[A]
+    const float value = [&] {
+      float v = 0.f;
+#pragma unroll
+      for (int a = 0; a < A1; ++a)
+        if (a == A)
+          v = z[a];
+      return v;
+    }();
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A)
+        mx = fmaxf(mx, z[a]);
+    float se = 0.f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      if (a < A)
+        se += expf(z[a] - mx);
+    const float lse = mx + logf(se);
+    const int ai = act[row];
+    float lp[AMAX], p[AMAX], ent = 0.f, lpa = 0.f, olpa = 0.f;
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+      lp[a] = 0.f;
+      p[a] = 0.f;
+      if (a < A) {
+        lp[a] = z[a] - lse;            // losses.cc:45-47
+        p[a] = expf(lp[a]);
+        ent += p[a] * lp[a];           // losses.cc:41-43
+        if (a == ai) {
+          lpa = lp[a];
+          olpa = oldlp[(size_t)row * A + a];
+        }
+      }
+    }
+    ent = -ent;
+    const float advi = adv[row], reti = ret[row];
+    const float rho = expf(lpa - olpa);                                  // losses.cc:33
+    const float crho = fminf(fmaxf(rho, 1.0f - hp.clip), 1.0f + hp.clip); // losses.cc:34-35
+    const float un = rho * advi, cl = crho * advi;
+    const float obj = fminf(un, cl);                                     // losses.cc:38
+    const float dv = value - reti;
+    const float lv = 0.5f * (dv * dv);                                   // losses.cc:15
+    const float Ltot = -obj + hp.c_v * lv - hp.c_e * ent;                // losses.cc:17-18
+    const float m = mask[row] ? inv_nm : 0.f;                            // losses.cc:19 masked mean
+    const bool active = advi >= 0.f ? (rho <= 1.0f + hp.clip) : (rho >= 1.0f - hp.clip);
+    const float gs = active ? -rho * advi : 0.f;
+    float dz[A1];
+#pragma unroll
+    for (int a = 0; a < A1; ++a) {
+      dz[a] = 0.f;
+      if (a < A && a < AMAX)
+        dz[a] = m * (gs * ((a == ai ? 1.0f : 0.0f) - p[a < AMAX ? a : 0]) +
+                     hp.c_e * p[a < AMAX ? a : 0] * (lp[a < AMAX ? a : 0] + ent));
+      if (a == A)
+        dz[a] = m * hp.c_v * dv;
+    }
+    if (lane == 0) {
+      ps_total[row] = Ltot;
+      ps_clipped[row] = obj;
+      ps_value[row] = lv;
+      ps_entropy[row] = ent;
+      ps_ratio[row] = rho;
+      if (logits_out) {
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a)
+          if (a < A)
+            logits_out[(size_t)row * A + a] = z[a];
+        values_out[row] = value;
+      }
+    }
+    // head dgrad: dh = sum_a dz[a] * W[a][:]   and wgrad partial: gW[a][:] += dz[a] * h
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) {
+      const int j = lane + 64 * i;
+      if (j < H) {
+        float d = 0.f;
+#pragma unroll
+        for (int a = 0; a < A1; ++a)
+          if (a <= A) {
+            d += dz[a] * sW[a * H + j];
+            gW[a][i] += dz[a] * hv[i];
+          }
+        dh[(size_t)row * H + j] = (T)d;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < A1; ++a)
+      gb[a] += dz[a];
+  }
+  // ordered cross-wave accumulation (deterministic)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < A1; ++a)
+        if (a <= A) {
+#pragma unroll
+          for (int i = 0; i < HPL; ++i) {
+            const int j = lane + 64 * i;
+            if (j < H)
+              sAcc[a * H + j] += gW[a][i];
+          }
+          if (lane == 0)
+            sB[w * A1 + a] = gb[a];
+        }
+    }
+    __syncthreads();
+  }
+  float *ow = slab_w + (size_t)blockIdx.x * (A + 1) * H;
+  for (int i = tid; i < (A + 1) * H; i += 256)
+    ow[i] = sAcc[i];
+  if (tid <= A)
+    slab_b[(size_t)blockIdx.x * (A + 1) + tid] = (sB[tid] + sB[A1 + tid]) + (sB[2 * A1 + tid] + sB[3 * A1 + tid]);
+}
+
+template <class T>
+static void head_train_t(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
+                         const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
+                         const float *mask_count, Hyper hp, void *dh, float *ps_total, float *ps_clipped,
+                         float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
+                         long B, int H, int A, float *lo, float *vo) {
+#define LAUNCH_HEAD(AM)                                                                                                \
+  do {                                                                                                                 \
+    const size_t sm = ((size_t)2 * (AM + 1) * H + 4 * (AM + 1)) * sizeof(float);                                       \
+    if (sm > 48 * 1024)                                                                                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&head_train_kernel<T, AM>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
+    hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(256), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
+                       mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
+                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo);                                                     \
+  } while (0)
+  if (A <= 4)
+    LAUNCH_HEAD(4);
+  else if (A <= 6)
+    LAUNCH_HEAD(6);
+  else
+    LAUNCH_HEAD(18);
+#undef LAUNCH_HEAD
+}
+void launch_head_train(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
+                       const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
+                       const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
+                       float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
+                       long B, int H, int A, float *logits_out, float *values_out) {
+  if (prec == ALEPPO_BF16)
+    head_train_t<bf16>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
+                       ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out);
+  else
+    head_train_t<float>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
+                        ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out);
+}
+
+// ================================================================================================
+// Split-K slab reduction -> flat gradient (fixed summation order => run-to-run deterministic).
+// ================================================================================================
+struct ReduceArgs {
+  ReduceSeg seg[12];
+  long prefix[13];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(ReduceArgs a, float *G) {
+  const long total = a.prefix[a.nseg];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int s = 0;
+    while (i >= a.prefix[s + 1])
+      ++s;
+    const long j = i - a.prefix[s];
+    const float *p = a.seg[s].slab + j;
+    const long n = a.seg[s].n;
+    float acc = 0.f;
+    for (int k = 0; k < a.seg[s].S; ++k)
+      acc += p[(long)k * n];
+    G[a.seg[s].dst + j] = acc;
+  }
+}
+void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *G) {
+  ReduceArgs a;
+  a.nseg = nseg;
+  a.prefix[0] = 0;
+  for (int i = 0; i < nseg; ++i) {
+    a.seg[i] = segs[i];
+    a.prefix[i + 1] = a.prefix[i] + segs[i].n;
+  }
+  const long total = a.prefix[nseg];
+  const int nb = (int)std::min<long>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, a, G);
+}
+
+// ================================================================================================
+// clip_grad_norm_ (train.cc:12-46) + torch::optim::Adam (eps 1e-5, train.cc:360-362) in two kernels:
+// per-block sum of squares, then every Adam block re-reduces the <=1024 partials in the same order
+// (identical norm everywhere), scales by min(1, max_norm/(norm+1e-6)) and applies the update.  The
+// bf16 compute copy of the weights is refreshed in the same pass.
+// ================================================================================================
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ G, long n, float *partials) {
+  __shared__ float s4[4];
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long b = (long)blockIdx.x * per, e = min(n, b + per);
+  float s = 0.f;
+  for (long i = b + threadIdx.x; i < e; i += 256)
+    s += G[i] * G[i];
+  s = block_sum_256(s, s4);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = s;
+}
+void launch_sumsq(hipStream_t s, const float *G, long n, float *partials, int nblk) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, G, n, partials);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__restrict__ G, float *Gs, float *M1, float *M2,
+                                                    T *Pc, long n, const float *__restrict__ partials, int nblk,
+                                                    float max_norm, float step_size, float bc2_sqrt, float beta1,
+                                                    float beta2, float eps, float *grad_norm_out) {
+  __shared__ float s4[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256)
+    s += partials[i];
+  s = block_sum_256(s, s4);
+  const float norm = sqrtf(s);
+  float coef = max_norm / (norm + 1e-6f); // train.cc:39
+  coef = fminf(coef, 1.0f);               // train.cc:40-41
+  if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm_out)
+    *grad_norm_out = norm;                // pre-clip norm is what the reference reports (Q9)
+  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = G[i] * coef;          // train.cc:42-44 (always applied)
+    const float m = M1[i] * beta1 + omb1 * g;
+    const float v = M2[i] * beta2 + omb2 * (g * g);
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    const float p = P[i] - step_size * (m / denom);
+    M1[i] = m;
+    M2[i] = v;
+    P[i] = p;
+    if (Gs)
+      Gs[i] = g;
+    if (Pc)
+      Pc[i] = (T)p;
+  }
+}
+void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
+                 int prec, long n, const float *partials, int nblk, float max_norm, float step_size, float bc2_sqrt,
+                 float beta1, float beta2, float eps, float *grad_norm_out) {
+  const int nb = (int)std::min<long>((n + 255) / 256, 2048);
+  if (prec == ALEPPO_BF16)
+    hipLaunchKernelGGL(adam_kernel<bf16>, dim3(nb), dim3(256), 0, s, P, G_in, G_out_scaled, M1, M2,
+                       static_cast<bf16 *>(Pc), n, partials, nblk, max_norm, step_size, bc2_sqrt, beta1, beta2, eps,
+                       grad_norm_out);
+  else
+    hipLaunchKernelGGL(adam_kernel<float>, dim3(nb), dim3(256), 0, s, P, G_in, G_out_scaled, M1, M2,
+                       static_cast<float *>(nullptr), n, partials, nblk, max_norm, step_size, bc2_sqrt, beta1, beta2,
+                       eps, grad_norm_out);
+}
+
+__global__ void cast_params_kernel(const float *P, bf16 *Pc, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    Pc[i] = (bf16)P[i];
+}
+void launch_cast_params(hipStream_t s, const float *P, void *Pc, long n) {
+  hipLaunchKernelGGL(cast_params_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, P,
+                     static_cast<bf16 *>(Pc), n);
+}
+
+// dgrad-side weight copies: W3d[c][(kh,kw,oc)], W2d[class][c][(a,b,oc)], WfcT[j][o]   (all in T)
+template <class T> __global__ void pack_conv_dgrad_kernel(const float *W3, const float *W2, T *W3d, T *W2d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 64 * 576) {
+    const int c = i / 576, rem = i - c * 576, tap = rem >> 6, oc = rem & 63;
+    W3d[i] = (T)W3[oc * 576 + tap * 64 + c];
+  } else if (i < 64 * 576 + 4 * 32 * 256) {
+    const int k = i - 64 * 576;
+    const int cls = k / (32 * 256), c = (k / 256) % 32, rem = k & 255, ab = rem >> 6, oc = rem & 63;
+    const int kh = (cls >> 1) + 2 * (ab >> 1), kw = (cls & 1) + 2 * (ab & 1);
+    W2d[k] = (T)W2[oc * 512 + (kh * 4 + kw) * 32 + c];
+  }
+}
+template <class T> __global__ void transpose_cast_kernel(const float *in, T *out, int R, int C) { // out[C][R]
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32x8
+  for (int k = ty; k < 32; k += 8)
+    if (r0 + k < R && c0 + tx < C)
+      tile[k][tx] = in[(size_t)(r0 + k) * C + c0 + tx];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < C && r0 + tx < R)
+      out[(size_t)(c0 + k) * R + r0 + tx] = (T)tile[tx][k];
+}
+void launch_pack_dgrad(hipStream_t s, const float *P, const ParamLayout &L, void *W2d, void *W3d, void *WfcT,
+                       int prec) {
+  const int n = 64 * 576 + 4 * 32 * 256;
+  const dim3 tg((FC_IN + 31) / 32, (L.H + 31) / 32);
+  if (prec == ALEPPO_BF16) {
+    hipLaunchKernelGGL(pack_conv_dgrad_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, P + L.off[P_W3],
+                       P + L.off[P_W2], static_cast<bf16 *>(W3d), static_cast<bf16 *>(W2d));
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16>, tg, dim3(256), 0, s, P + L.off[P_WFC], static_cast<bf16 *>(WfcT),
+                       L.H, FC_IN);
+  } else {
+    hipLaunchKernelGGL(pack_conv_dgrad_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, P + L.off[P_W3],
+                       P + L.off[P_W2], static_cast<float *>(W3d), static_cast<float *>(W2d));
+    hipLaunchKernelGGL(transpose_cast_kernel<float>, tg, dim3(256), 0, s, P + L.off[P_WFC],
+                       static_cast<float *>(WfcT), L.H, FC_IN);
+  }
+}
+
+// masked sums of the per-sample metric arrays (log_data's masked means, train.cc:163-210): block per (epoch, mb)
+__global__ __launch_bounds__(256) void metrics_reduce_kernel(const float *ps, size_t field_stride, const uint8_t *mask_n,
+                                                              long B, int M, float *out) {
+  __shared__ float s4[4];
+  const int mi = blockIdx.x, mb = mi % M;
+  const uint8_t *m = mask_n + (size_t)mb * B;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, cnt = 0.f;
+  for (long i = threadIdx.x; i < B; i += 256)
+    if (m[i]) {
+      cnt += 1.f;
+#pragma unroll
+      for (int f = 0; f < 5; ++f)
+        acc[f] += ps[f * field_stride + (size_t)mi * B + i];
+    }
+#pragma unroll
+  for (int f = 0; f < 5; ++f) {
+    const float v = block_sum_256(acc[f], s4);
+    if (threadIdx.x == 0)
+      out[mi * 8 + f] = v;
+  }
+  cnt = block_sum_256(cnt, s4);
+  if (threadIdx.x == 0)
+    out[mi * 8 + 5] = cnt;
+}
+void launch_metrics_reduce(hipStream_t s, const float *ps, size_t field_stride, const uint8_t *mask_n, long B, int M,
+                           int epochs, float *out) {
+  hipLaunchKernelGGL(metrics_reduce_kernel, dim3(epochs * M), dim3(256), 0, s, ps, field_stride, mask_n, B, M, out);
+}
+
+// ================================================================================================
+// Boundary-only layout conversions (parity dumps / caller-supplied batches; not on the hot path).
+// ================================================================================================
+__global__ void obs_unpack_kernel(const uint32_t *obs, uint8_t *out, SampleMap map) { // -> NCHW u8 [n][4][7056]
+  const long n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= FRAME_PIX)
+    return;
+  const uint32_t w = obs[(n / map.TP) * map.s1 + (n % map.TP) * map.s0 + map.base + i];
+  uint8_t *o = out + (size_t)n * 4 * FRAME_PIX + i;
+  o[0] = w & 255u;
+  o[FRAME_PIX] = (w >> 8) & 255u;
+  o[2 * FRAME_PIX] = (w >> 16) & 255u;
+  o[3 * FRAME_PIX] = w >> 24;
+}
+__global__ void obs_pack_kernel(const uint8_t *in, uint32_t *obs, SampleMap map) {
+  const long n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= FRAME_PIX)
+    return;
+  const uint8_t *p = in + (size_t)n * 4 * FRAME_PIX + i;
+  obs[(n / map.TP) * map.s1 + (n % map.TP) * map.s0 + map.base + i] =
+      (uint32_t)p[0] | ((uint32_t)p[FRAME_PIX] << 8) | ((uint32_t)p[2 * FRAME_PIX] << 16) |
+      ((uint32_t)p[3 * FRAME_PIX] << 24);
+}
+void launch_obs_unpack(hipStream_t s, const uint32_t *obs, uint8_t *out, long nsamp, SampleMap map) {
+  hipLaunchKernelGGL(obs_unpack_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)nsamp), dim3(256), 0, s, obs, out, map);
+}
+void launch_obs_pack(hipStream_t s, const uint8_t *in, uint32_t *obs, long nsamp, SampleMap map) {
+  hipLaunchKernelGGL(obs_pack_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)nsamp), dim3(256), 0, s, in, obs, map);
+}
+
+// [T][E][inner] (elements of `elem` bytes, row pitch src_pitch bytes per t) -> [E][T][inner]
+__global__ void transpose_tm_kernel(const uint8_t *src, size_t src_pitch, uint8_t *dst, int E, int T, int inner,
+                                    int elem) {
+  const long total = (long)E * T * inner;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % inner);
+    const long et = i / inner;
+    const int t = (int)(et % T), e = (int)(et / T);
+    const uint8_t *s = src + (size_t)t * src_pitch + ((size_t)e * inner + k) * elem;
+    uint8_t *d = dst + (size_t)i * elem;
+    for (int b = 0; b < elem; ++b)
+      d[b] = s[b];
+  }
+}
+void launch_transpose_tm_pitched(hipStream_t s, const void *src_tm, size_t pitch, void *dst_em, int E, int T, int inner,
+                                 int elem) {
+  hipLaunchKernelGGL(transpose_tm_kernel, dim3(256), dim3(256), 0, s, static_cast<const uint8_t *>(src_tm), pitch,
+                     static_cast<uint8_t *>(dst_em), E, T, inner, elem);
+}
+
+// action/value heads only (aleppo_forward): one wave per row
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float *__restrict__ h, const float *__restrict__ Wh,
+                                                         const float *__restrict__ bh, float *logits, float *values,
+                                                         long n, int H, int A) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= n)
+    return;
+  for (int a = 0; a <= A; ++a) {
+    float s = 0.f;
+    for (int j = lane; j < H; j += 64)
+      s += h[(size_t)r * H + j] * Wh[(size_t)a * H + j];
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (a < A)
+        logits[r * A + a] = s + bh[a];
+      else
+        values[r] = s + bh[a];
+    }
+  }
+}
+void launch_heads_fwd(hipStream_t s, const float *h, const float *Wh, const float *bh, float *logits, float *values,
+                      long n, int H, int A) {
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, h, Wh, bh, logits, values, n, H,
+                     A);
+}
+
+__global__ void logsoftmax_rows_kernel(const float *in, float *out, long rows, int A) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows)
+    return;
+  const float *z = in + r * A;
+  float mx = z[0];
+  for (int k = 1; k < A; ++k)
+    mx = fmaxf(mx, z[k]);
+  float s = 0.f;
+  for (int k = 0; k < A; ++k)
+    s += expf(z[k] - mx);
+  const float lse = mx + logf(s);
+  for (int k = 0; k < A; ++k)
+    out[r * A + k] = z[k] - lse;
+}
+void launch_logsoftmax_rows(hipStream_t s, const float *in, float *out, long rows, int A) {
+  hipLaunchKernelGGL(logsoftmax_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, in, out, rows, A);
+}
+
+// ================================================================================================
+// Stateless operators of the reference's free functions (parity tests).
+// ================================================================================================
+// vision.cc:8-32 interpolate(mode=area) 210x160 -> 84x84, float in / float out
+__global__ void area_resize_kernel(const float *in, float *out) {
+  const long n = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= FRAME_PIX)
+    return;
+  const int i = pix / 84, j = pix - i * 84;
+  const int y0 = (i * RAW_H) / 84, y1 = ((i + 1) * RAW_H + 83) / 84, x0 = (j * RAW_W) / 84,
+            x1 = ((j + 1) * RAW_W + 83) / 84;
+  const float *src = in + (size_t)n * RAW_H * RAW_W;
+  float s = 0.f;
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x)
+      s += src[y * RAW_W + x];
+  out[(size_t)n * FRAME_PIX + pix] = s / (float)((y1 - y0) * (x1 - x0));
+}
+void launch_area_resize(hipStream_t s, const float *in, float *out, long n) {
+  hipLaunchKernelGGL(area_resize_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)n), dim3(256), 0, s, in, out);
+}
+// vision.cc:51,71-84
+__global__ void rgb_to_gray_kernel(const float *in, float *out) {
+  const long n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= FRAME_PIX)
+    return;
+  const float *s = in + (size_t)n * 3 * FRAME_PIX + p;
+  out[(size_t)n * FRAME_PIX + p] =
+      __fadd_rn(__fadd_rn(__fmul_rn(s[0], 0.2125f), __fmul_rn(s[FRAME_PIX], 0.7154f)), __fmul_rn(s[2 * FRAME_PIX], 0.0721f));
+}
+void launch_rgb_to_gray(hipStream_t s, const float *in, float *out, long n) {
+  hipLaunchKernelGGL(rgb_to_gray_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)n), dim3(256), 0, s, in, out);
+}
+// fused device preprocessing alone: [n][2][210][160] u8 -> [n][84][84] u8 (same arithmetic as ingest_kernel<true>)
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ lut,
+                                                          uint8_t *out) {
+  const int e = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t sraw[2 * 30 * RAW_W];
+  __shared__ uint8_t slut[256];
+  for (int v = tid; v < 600; v += 256) {
+    const int f = v / 300, r = v - f * 300;
+    const u32x4 *src =
+        reinterpret_cast<const u32x4 *>(raw + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)band * 30 * RAW_W);
+    reinterpret_cast<u32x4 *>(sraw)[v] = src[r];
+  }
+  slut[tid] = lut ? lut[tid] : (uint8_t)tid;
+  __syncthreads();
+  for (int pix = tid; pix < 12 * 84; pix += 256) {
+    const int il = pix / 84, j = pix - il * 84, i = band * 12 + il;
+    const int y0 = (i * RAW_H) / 84 - band * 30, y1 = ((i + 1) * RAW_H + 83) / 84 - band * 30;
+    const int x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84;
+    int best = 0;
+    for (int f = 0; f < 2; ++f) {
+      int s = 0;
+      for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x)
+          s += slut[sraw[(f * 30 + y) * RAW_W + x]];
+      best = max(best, (int)rintf((float)s / (float)((y1 - y0) * (x1 - x0))));
+    }
+    out[(size_t)e * FRAME_PIX + i * 84 + j] = (uint8_t)min(best, 255);
+  }
+}
+void launch_preprocess(hipStream_t s, const uint8_t *raw, const uint8_t *lut, uint8_t *out, long n) {
+  hipLaunchKernelGGL(preprocess_kernel, dim3(7, (unsigned)n), dim3(256), 0, s, raw, lut, out);
+}
+// rollout.cc:184-196 on reference-layout NCHW u8 [E][4][84][84]
+__global__ void update_obs_nchw_kernel(uint8_t *obs, const uint8_t *frames, const uint8_t *start) {
+  const long e = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= FRAME_PIX)
+    return;
+  uint8_t *o = obs + (size_t)e * 4 * FRAME_PIX + i;
+  const uint8_t f = frames[(size_t)e * FRAME_PIX + i];
+  if (start[e]) {
+    o[0] = o[FRAME_PIX] = o[2 * FRAME_PIX] = o[3 * FRAME_PIX] = f;
+  } else {
+    o[3 * FRAME_PIX] = o[2 * FRAME_PIX];
+    o[2 * FRAME_PIX] = o[FRAME_PIX];
+    o[FRAME_PIX] = o[0];
+    o[0] = f;
+  }
+}
+void launch_update_obs_nchw(hipStream_t s, uint8_t *obs, const uint8_t *frames, const uint8_t *start, long E) {
+  hipLaunchKernelGGL(update_obs_nchw_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)E), dim3(256), 0, s, obs, frames,
+                     start);
+}
+
+// losses.cc:4-47 forward + closed-form backward on raw logits, one thread per sample; block 0 reduces the loss
+__global__ __launch_bounds__(256) void ppo_loss_op_kernel(const float *logits, const float *oldlp, const int64_t *actions,
+                                                           const float *adv, const float *values, const float *ret,
+                                                           const uint8_t *mask, long B, int A, Hyper hp, float *loss,
+                                                           float *clipped, float *value_losses, float *entropies,
+                                                           float *total_losses, float *ratio, float *dlogits,
+                                                           float *dvalues) {
+  __shared__ float s4[4];
+  float cnt = 0.f;
+  for (long i = threadIdx.x; i < B; i += 256)
+    cnt += mask[i] ? 1.f : 0.f;
+  cnt = block_sum_256(cnt, s4);
+  float lsum = 0.f;
+  for (long i = threadIdx.x; i < B; i += 256) {
+    const float *z = logits + i * A;
+    float mx = z[0];
+    for (int k = 1; k < A; ++k)
+      mx = fmaxf(mx, z[k]);
+    float se = 0.f;
+    for (int k = 0; k < A; ++k)
+      se += expf(z[k] - mx);
+    const float lse = mx + logf(se);
+    const int ai = (int)actions[i];
+    float ent = 0.f;
+    for (int k = 0; k < A; ++k) {
+      const float lp = z[k] - lse;
+      ent += expf(lp) * lp;
+    }
+    ent = -ent;
+    const float lpa = z[ai] - lse;
+    const float rho = expf(lpa - oldlp[i * A + ai]);
+    const float crho = fminf(fmaxf(rho, 1.0f - hp.clip), 1.0f + hp.clip);
+    const float obj = fminf(rho * adv[i], crho * adv[i]);
+    const float dv = values[i] - ret[i];
+    const float lv = 0.5f * (dv * dv);
+    const float L = -obj + hp.c_v * lv - hp.c_e * ent;
+    if (mask[i])
+      lsum += L;
+    if (clipped) clipped[i] = obj;
+    if (value_losses) value_losses[i] = lv;
+    if (entropies) entropies[i] = ent;
+    if (total_losses) total_losses[i] = L;
+    if (ratio) ratio[i] = rho;
+    if (dlogits) {
+      const float m = mask[i] ? 1.0f / cnt : 0.f;
+      const bool active = adv[i] >= 0.f ? (rho <= 1.0f + hp.clip) : (rho >= 1.0f - hp.clip);
+      const float gs = active ? -rho * adv[i] : 0.f;
+      for (int k = 0; k < A; ++k) {
+        const float lp = z[k] - lse, p = expf(lp);
+        dlogits[i * A + k] = m * (gs * ((k == ai ? 1.f : 0.f) - p) + hp.c_e * p * (lp + ent));
+      }
+      dvalues[i] = m * hp.c_v * dv;
+    }
+  }
+  lsum = block_sum_256(lsum, s4);
+  if (threadIdx.x == 0 && loss)
+    *loss = lsum / cnt;
+}
+void launch_ppo_loss_op(hipStream_t s, const float *logits, const float *oldlp, const int64_t *actions,
+                        const float *adv, const float *values, const float *ret, const uint8_t *mask, long B, int A,
+                        Hyper hp, float *loss, float *clipped, float *value_losses, float *entropies,
+                        float *total_losses, float *ratio, float *dlogits, float *dvalues) {
+  hipLaunchKernelGGL(ppo_loss_op_kernel, dim3(1), dim3(256), 0, s, logits, oldlp, actions, adv, values, ret, mask, B,
+                     A, hp, loss, clipped, value_losses, entropies, total_losses, ratio, dlogits, dvalues);
+}
+// train.cc:374-375 given the exponential noise: argmax(p/q), first max wins; IEEE division -> bit-exact
+__global__ void sample_op_kernel(const float *probs, const float *q, int64_t *actions, long E, int A) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E)
+    return;
+  int best = 0;
+  float bv = __fdiv_rn(probs[e * A], q[e * A]);
+  for (int k = 1; k < A; ++k) {
+    const float v = __fdiv_rn(probs[e * A + k], q[e * A + k]);
+    if (v > bv) {
+      bv = v;
+      best = k;
+    }
+  }
+  actions[e] = best;
+}
+void launch_sample_op(hipStream_t s, const float *probs, const float *q, int64_t *actions, long E, int A) {
+  hipLaunchKernelGGL(sample_op_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, probs, q, actions, E, A);
+}
+
+} // namespace aleppo

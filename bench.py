@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/s of the MI355X-native PPO-over-ALE hot path on synthetic 84x84x4 uint8 batches.
+
+One "step" = one pass of the hot path over one rollout batch: for each of T slots  act (Nature-CNN
+forward + categorical sample)  ->  ingest (raw frame pair -> LUT -> 84x84 area resize -> 2-frame max ->
+4-frame stack -> rollout slot)  ->  record, then bootstrap + reward-clamp/GAE/returns, then the PPO
+update (epochs x minibatches of forward / loss / backward / [RCCL all-reduce] / clip / Adam).
+Synthetic inputs are resident in HBM before the timed region.  value = env-steps of all ranks / time,
+counting (like the reference, rollout.cc:225) only non-episode-start slots.
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run
+(one rank per GPU, RCCL).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+# algorithmic FLOPs per sample of each conv/linear kernel (2*MAC), SURVEY 8(d): fwd 18.69, fwd+bwd 49.52 MFLOP
+KFLOP = dict(conv1_fwd=2 * 400 * 32 * 256, conv2_fwd=2 * 81 * 64 * 512, conv3_fwd=2 * 49 * 64 * 576,
+             fc_fwd=2 * 3136 * 512, fc_dgrad=2 * 3136 * 512, fc_wgrad=2 * 3136 * 512, conv3_dgrad=2 * 49 * 64 * 576,
+             conv3_wgrad=2 * 49 * 64 * 576, conv2_dgrad=2 * 81 * 64 * 512, conv2_wgrad=2 * 81 * 64 * 512,
+             conv1_wgrad=2 * 400 * 32 * 256)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_step_inputs(rng, E, T):
+    """per-slot host scalars: rewards in {0,1,4,7} w.p. 0.05; terminated p=1/200, truncated p=1/2000,
+    each followed by one episode-start slot."""
+    rewards = np.zeros((T, E), np.float32)
+    term = np.zeros((T, E), np.uint8)
+    trunc = np.zeros((T, E), np.uint8)
+    start = np.zeros((T, E), np.uint8)
+    return rewards, term, trunc, start
+
+
+def run(args):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    pkg = load_package()
+
+    E, T, A, H = args.envs, args.horizon, args.actions, 512
+    epochs, M = args.epochs, args.minibatches
+    prec = pkg.BF16 if args.dtype == "bf16" else pkg.FP32
+    eng = pkg.Engine(E, T, A, H, precision=prec, device=local_rank, world_size=world, rank=rank, seed=42 + rank,
+                     max_minibatch=E * T // M)
+    if world > 1:
+        uid = [pkg.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0])
+    # random-init weights of the reference architecture (orthogonal init is not reproduced; He-uniform fill)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashfill as hf
+    eng.load_params(hf.fill_params(310, H, A))
+    lut = (np.arange(256) // 2 * 2).astype(np.uint8)
+    eng.set_gray_lut(lut)
+
+    # synthetic raw frame pairs for every slot, resident in HBM: [T][E][2][210][160] uint8 palette codes
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42 + rank)
+    frames = (torch.randint(0, 128, (T, E, 2, 210, 160), device="cuda", generator=g, dtype=torch.int16) * 2).to(
+        torch.uint8)
+    slot_bytes = E * 2 * 210 * 160
+    base_ptr = frames.data_ptr()
+    rng = np.random.default_rng(42 + rank)
+
+    start = np.ones(E, np.uint8)
+    rewards = np.zeros(E, np.float32)
+    real_steps = 0
+
+    def one_rollout_and_update(count):
+        nonlocal start, rewards, real_steps
+        for t in range(T):
+            eng.act()  # forward + sample; actions land in pinned host memory (an emulator would read them here)
+            u = rng.random(E)
+            term = ((u < 1 / 200) & (start == 0)).astype(np.uint8)
+            trunc = ((u >= 1 / 200) & (u < 1 / 200 + 1 / 2000) & (start == 0)).astype(np.uint8)
+            r = np.where(rng.random(E) < 0.05, rng.choice([1.0, 4.0, 7.0], E), 0.0).astype(np.float32)
+            rewards = np.where(start == 1, rewards, r).astype(np.float32)
+            eng.step(None, rewards, term, trunc, start, kind=pkg.FRAMES_RAW_PAIR, device_ptr=base_ptr + t * slot_bytes)
+            if count:
+                real_steps += int((start == 0).sum())
+            start = (term | trunc).astype(np.uint8)
+        eng.finish_rollout()
+        return eng.train(2.5e-4, epochs, M)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_rollout_and_update(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        metrics = one_rollout_and_update(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    steps_all = torch.tensor([float(real_steps)], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(steps_all, op=dist.ReduceOp.SUM)
+    dt = tmax.item()
+    value = steps_all.item() / dt
+
+    # ---- separate profiling pass (HIP events around every launch, on the stream the kernels run on)
+    roofline = None
+    kern = {}
+    if rank == 0:
+        eng.profile(True)
+        eng.profile_reset()
+        one_rollout_and_update(False)
+        for k in pkg.KERNEL_CLASSES:
+            kern[k] = eng.profile_read(k)
+        eng.profile(False)
+        B = E * T // M
+        n_train = epochs * M
+        # training launches of the fwd kernels are the last n_train ... simpler: total time split by launch count
+        tot = {}
+        for k, (ms, n) in kern.items():
+            tot[k] = ms * n
+        gemm = {k: v for k, v in tot.items() if k in KFLOP}
+        dom = max(gemm, key=gemm.get)
+        # fwd kernels also ran (T+1) acting launches of E samples in this pass: use per-sample flops x samples seen
+        samples = B * n_train + (E * (T + 1) if dom.endswith("_fwd") else 0)
+        achieved = KFLOP[dom] * samples / (tot[dom] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(achieved / peak, 4), traffic=None,
+                        avg_launch_ms=round(kern[dom][0], 4), launches=kern[dom][1])
+        # HBM-bound leg: ingest (74,256 B per env-step algorithmic) and GAE (23 B per (env,t))
+        ing_ms, ing_n = kern["ingest"]
+        gae_ms, gae_n = kern["gae"]
+        hbm = dict(ingest_GBps=round(74256 * E / (ing_ms * 1e-3) / 1e9, 1) if ing_ms else None,
+                   ingest_frac=round(74256 * E / (ing_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if ing_ms else None,
+                   gae_GBps=round(23 * E * T / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else None,
+                   adam_GBps=round(28 * eng.param_count / (kern["adam"][0] * 1e-3) / 1e9, 1) if kern["adam"][0] else None)
+        roofline["hbm_kernels"] = hbm
+        roofline["per_kernel_ms"] = {k: round(v[0], 4) for k, v in kern.items()}
+        all_gemm_ms = sum(gemm.values())
+        flops = sum(KFLOP[k] * (B * n_train + (E * (T + 1) if k.endswith("_fwd") else 0)) for k in gemm)
+        roofline["all_gemm_TFLOPs"] = round(flops / (all_gemm_ms * 1e-3) / 1e12, 2)
+
+    # ---- CPU baseline beside it (rank 0, N=1 only): the reference's own compiled CPU-libtorch path
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "env steps/sec (whole node), Breakout 84x84x4", "value": round(value, 1),
+            "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Breakout-shaped synthetic, {E} envs/GPU x T={T}, A={A}, H=512, "
+                                   f"{epochs} epochs x {M} minibatches of {E * T // M} (configs[1], v0.yaml update shape)",
+                       "envs_per_gpu": E, "horizon": T, "epochs": epochs, "minibatches": M,
+                       "parallelism": f"dp{world}", "frames": "raw u8 [E,2,210,160] pairs resident in HBM"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "vs_reference_published_v1_26289": round(value / 26289.0, 2),
+            "last_loss": float(metrics["loss"][-1, -1]), "last_grad_norm": float(metrics["grad_norm"][-1, -1]),
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline():
+    """time oracle/_ref/ref_harness (the reference's compiled gae.cc/buffer.cc/losses.cc/train.{h,cc} on
+    CPU libtorch) on a bounded sample: configs/v0.yaml shape (8 envs, T=128, 4 epochs x 4 minibatches)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    threads = os.cpu_count() or 1
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, "bench", "8", "128", "512", "4", "4", "4", "8", str(threads)], check=True,
+                                 capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+            j = json.loads(out)
+            return {"value": round(j["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": threads,
+                    "kind": "reference",
+                    "sample": "configs/v0.yaml shape: 8 envs x T=128, 4 epochs x 4 minibatches of 256, H=512, "
+                              f"8 rollouts+updates after 1 warm-up ({j['seconds']:.1f} s), libtorch CPU"}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"reference cpu baseline failed ({e}); falling back to the C port\n")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashfill as hf
+    import oracle_lib as orc
+    H, A, N, M, ep = 512, 4, 256, 4, 1
+    params = hf.fill_params(310, H, A)
+    obs = hf.hf_bytes(5, (N, 4, 84, 84))
+    t0 = time.perf_counter()
+    orc.train(params, H, A, obs, np.zeros(N, np.int64), orc.log_softmax(np.zeros((N, A), np.float32)),
+              np.ones(N, np.float32), np.ones(N, np.float32), np.ones(N, np.uint8), ep, M)
+    dt = time.perf_counter() - t0
+    return {"value": round(N / dt / 4, 1), "unit": "env-steps/s", "cores": orc.lib().oracle_num_threads(),
+            "kind": "port", "sample": "oracle C port: 256 samples x 1 epoch update, scaled to 4 epochs"}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=128, help="environments per GPU (configs[1]: 128)")
+    ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--actions", type=int, default=4)
+    ap.add_argument("--epochs", type=int, default=4)
+    ap.add_argument("--minibatches", type=int, default=4)
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    run(ap.parse_args())

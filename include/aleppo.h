@@ -218,13 +218,24 @@ int aleppo_sample(int device_ordinal, const float *probs, const float *q, int64_
  * Average device time in ms of the named kernel class over the calls since the last reset, measured
  * with HIP events on the stream the kernels run on; *launches gets the number of timed launches. */
 typedef enum {
-  ALEPPO_K_INGEST = 0,   /* preprocess + frame stack + buffer write */
-  ALEPPO_K_GAE = 1,
-  ALEPPO_K_HEAD = 2,     /* heads + PPO loss fwd/bwd */
-  ALEPPO_K_ADAM = 3,     /* clip + Adam */
-  ALEPPO_K_TRAIN_GEMM = 4, /* all conv/linear forward+backward kernels of one minibatch */
-  ALEPPO_K_INFER_GEMM = 5, /* conv/linear forward kernels of one act() */
-  ALEPPO_K_COUNT = 6
+  ALEPPO_K_INGEST = 0,      /* preprocess + frame stack + rollout-slot write */
+  ALEPPO_K_GAE = 1,         /* reward clamp + GAE + returns + old log-probs */
+  ALEPPO_K_HEAD = 2,        /* heads + PPO loss forward/backward */
+  ALEPPO_K_ADAM = 3,        /* sum of squares + clip + Adam + dgrad weight repack */
+  ALEPPO_K_CONV1_FWD = 4,
+  ALEPPO_K_CONV2_FWD = 5,
+  ALEPPO_K_CONV3_FWD = 6,
+  ALEPPO_K_FC_FWD = 7,
+  ALEPPO_K_FC_DGRAD = 8,
+  ALEPPO_K_FC_WGRAD = 9,
+  ALEPPO_K_CONV3_DGRAD = 10,
+  ALEPPO_K_CONV3_WGRAD = 11,
+  ALEPPO_K_CONV2_DGRAD = 12,
+  ALEPPO_K_CONV2_WGRAD = 13,
+  ALEPPO_K_CONV1_WGRAD = 14,
+  ALEPPO_K_REDUCE = 15,     /* split-K slab reduction */
+  ALEPPO_K_INFER_HEAD = 16, /* action head + sampling */
+  ALEPPO_K_COUNT = 17
 } aleppo_kernel_class;
 int aleppo_profile_enable(aleppo_ctx *ctx, int on);
 int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);

@@ -1,0 +1,355 @@
+"""Parity tests proper (run on the MI355X: pytest -m gpu).  Every check goes through the C ABI of
+libaleppo.so (via the ctypes host mirror) and compares with
+  * the reference's golden outputs (tests/golden/ref_golden.npz, from the compiled reference), and
+  * the pinned CPU oracle (oracle/) on the same seeded inputs.
+Tolerances: integer / byte / index work bit-exact; fp32 1e-4 (north star), tighter where the
+arithmetic is order-identical; bf16 bounds are stated where used.
+"""
+import numpy as np
+import pytest
+
+import hashfill as hf
+import oracle_lib as orc
+from conftest import GAE_KATS, gae_kat_expected
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_package()
+    p.lib()
+    return p
+
+
+# ------------------------------------------------------------------ GAE (reads like test/ai/gae-test.cc)
+@pytest.mark.parametrize("k", range(6))
+def test_gae_known_answers(pkg, golden, k):
+    r, v, nv, te, tr, st = GAE_KATS[k]
+    adv = np.zeros(np.shape(r), np.float32)
+    pkg.gae.gae(adv, r, v, nv, te, tr, st, 0.99, 0.95)
+    np.testing.assert_allclose(adv, gae_kat_expected(r, v, nv, te, tr, st), atol=1e-5)
+    np.testing.assert_allclose(adv, golden[f"kat{k}_adv"], atol=1e-6)
+
+
+def test_gae_rejects_overlapping_flags(pkg):
+    with pytest.raises(pkg.AleppoInvalidArgument, match="mutually exclusive"):
+        pkg.gae.gae(np.zeros((1, 2), np.float32), [[1, 1]], [[0, 0]], [0], [[1, 0]], [[0, 0]], [[1, 0]], 0.99, 0.95)
+
+
+def test_gae_g1_matches_reference_buffer_get(pkg, golden):
+    r, v, nv, te, tr, st = hf.g1_inputs()
+    adv = np.zeros_like(r)
+    pkg.gae.gae(adv, np.clip(r, -1, 1), v, nv, te, tr, st, 0.99, 0.95)
+    np.testing.assert_allclose(adv, golden["g1_adv"], atol=2e-6)
+    np.testing.assert_array_equal(adv, orc.gae(np.clip(r, -1, 1), v, nv, te, tr, st))  # same op order: bit-exact
+
+
+def test_gae_ragged_shapes(pkg):
+    for E, T in [(1, 1), (3, 7), (65, 5), (130, 33)]:
+        r = hf.hf_range(11, (E, T), -1, 1)
+        v = hf.hf_range(12, (E, T), -1, 1)
+        nv = hf.hf_range(13, (E,), -1, 1)
+        u = hf.hf_unit(14, E * T).reshape(E, T)
+        te = (u < 0.05).astype(np.uint8)
+        tr = ((u >= 0.05) & (u < 0.08)).astype(np.uint8)
+        st = ((u >= 0.08) & (u < 0.12)).astype(np.uint8)
+        adv = np.zeros((E, T), np.float32)
+        pkg.gae.gae(adv, r, v, nv, te, tr, st, 0.99, 0.95)
+        np.testing.assert_array_equal(adv, orc.gae(r, v, nv, te, tr, st))
+
+
+# ------------------------------------------------------------------ vision (reads like test/ai/vision-test.cc)
+def test_vision_constant_preservation(pkg):
+    out = pkg.vision.resize_frame_stacked_grayscale_images(np.ones((1, 1, 210, 160), np.float32))
+    assert out.shape == (1, 1, 84, 84) and (out == 1).all()
+    inp = np.stack([np.full((210, 160), i, np.float32) for i in range(4)])[None]
+    out = pkg.vision.resize_frame_stacked_grayscale_images(inp)
+    assert out.shape == (1, 4, 84, 84) and out.dtype == np.float32
+    for i in range(4):
+        assert (out[0, i] == i).all()
+
+
+def test_vision_g7(pkg, golden):
+    inp = hf.hf_bytes(701, (1, 2, 210, 160)).astype(np.float32)
+    np.testing.assert_allclose(pkg.vision.resize_frame_stacked_grayscale_images(inp), golden["g7_area"], rtol=1e-6,
+                               atol=1e-4)
+    rgb = hf.hf_bytes(702, (1, 1, 3, 84, 84)).astype(np.float32)
+    np.testing.assert_allclose(pkg.vision.rgb_to_grayscale_frame_stacked_images(rgb), golden["g7_luma"], rtol=1e-6,
+                               atol=1e-4)
+
+
+def test_preprocess_bit_exact(pkg):
+    raw = hf.hf_bytes(711, (5, 2, 210, 160))
+    lut = ((np.arange(256) * 7 + 3) % 256).astype(np.uint8)
+    np.testing.assert_array_equal(pkg.vision.preprocess(raw, lut), orc.preprocess(raw, lut))
+    np.testing.assert_array_equal(pkg.vision.preprocess(raw), orc.preprocess(raw))
+    flat = np.full((1, 2, 210, 160), 77, np.uint8)  # constants survive (vision-test.cc property)
+    assert (pkg.vision.preprocess(flat) == 77).all()
+
+
+# ------------------------------------------------------------------ frame stack
+def _planes(obs):
+    o = obs.reshape(obs.shape[0], obs.shape[1], -1).astype(np.int64)
+    w = np.arange(1, o.shape[2] + 1, dtype=np.int64)
+    return np.stack([o.sum(-1), (o * w).sum(-1)], -1)
+
+
+def test_frame_stack_g6(pkg, golden):
+    E = 4
+    obs = np.zeros((E, 4, 84, 84), np.uint8)
+    for step in range(6):
+        frames = hf.hf_bytes(601 + step, (E, 84, 84))
+        start = np.array([step == 0 or (step == 3 and e == 1) or (step == 4 and e == 2) for e in range(E)], np.uint8)
+        obs = pkg.rollout.update_observations(obs, frames, start)
+        np.testing.assert_array_equal(_planes(obs), golden["g6_checksums"][step])
+    np.testing.assert_array_equal(obs[1], golden["g6_final_obs_env1"])
+
+
+# ------------------------------------------------------------------ PPO loss
+@pytest.mark.parametrize("A", [4, 6])
+def test_losses_g2(pkg, golden, A):
+    B = 256
+    logits = hf.hf_range(201 + A, (B, A), -2, 2)
+    actions = (hf.hf_u32(205 + A, B) % np.uint32(A)).astype(np.int64)
+    masks = (hf.hf_unit(209, B) >= np.float32(0.05)).astype(np.uint8)
+    s = f"g2_A{A}_"
+    o = pkg.losses.compute(logits, golden[s + "old_logp"], actions, hf.hf_range(206, (B,), -2, 2),
+                           hf.hf_range(207, (B,), -1, 1), hf.hf_range(208, (B,), -1.5, 1.5), masks, 0.1, 0.5, 0.01)
+    np.testing.assert_allclose(o.loss[0], golden[s + "loss"][0], atol=1e-5)
+    for k, g in (("clipped_losses", "clipped"), ("value_losses", "value_losses"), ("entropies", "entropies"),
+                 ("total_losses", "total_losses"), ("ratio", "ratio")):
+        np.testing.assert_allclose(getattr(o, k), golden[s + g], atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(o.dlogits, golden[s + "dlogits"], atol=1e-6)
+    np.testing.assert_allclose(o.dvalues, golden[s + "dvalues"], atol=1e-7)
+
+
+def test_losses_all_masked_and_single_row(pkg):
+    o = pkg.losses.compute([[0.1, 0.2, 0.3, 0.4]], orc.log_softmax([[0., 0., 0., 0.]]), [2], [1.0], [0.5], [1.0],
+                           [1], 0.2, 0.5, 0.01)
+    w = orc.ppo_loss([[0.1, 0.2, 0.3, 0.4]], orc.log_softmax([[0., 0., 0., 0.]]), [2], [1.0], [0.5], [1.0], [1],
+                     0.2, 0.5, 0.01)
+    np.testing.assert_allclose(o.loss[0], w["loss"], atol=1e-6)
+    np.testing.assert_allclose(o.dlogits, w["dlogits"], atol=1e-7)
+
+
+# ------------------------------------------------------------------ sampling: integer indices bit-exact
+@pytest.mark.parametrize("A", [4, 6])
+def test_sampling_g5_bit_exact(pkg, golden, A):
+    s = f"g5_A{A}_"
+    np.testing.assert_array_equal(pkg.sampling.multinomial_with_noise(golden[s + "probs"], golden[s + "q"]),
+                                  golden[s + "actions"])
+
+
+# ------------------------------------------------------------------ network forward
+@pytest.mark.parametrize("H,A", [(32, 4), (32, 6), (512, 4), (512, 6)])
+def test_forward_g3_fp32(pkg, golden, H, A):
+    eng = pkg.Engine(8, 1, A, H, precision=pkg.FP32)
+    eng.load_params(hf.fill_params(310, H, A))
+    np.testing.assert_allclose(eng.export_params(), hf.fill_params(310, H, A), atol=0)  # layout round trip
+    logits, values = eng.forward(hf.hf_bytes(301, (8, 4, 84, 84)))
+    np.testing.assert_allclose(logits, golden[f"g3_H{H}_A{A}_logits"], atol=1e-4)
+    np.testing.assert_allclose(values, golden[f"g3_H{H}_A{A}_values"], atol=1e-4)
+    eng.close()
+
+
+def test_forward_bf16_close(pkg, golden):
+    # bf16 operands (8-bit mantissa), fp32 accumulate: documented looser bound 3e-2 abs on O(1) outputs
+    H, A = 512, 6
+    eng = pkg.Engine(8, 1, A, H, precision=pkg.BF16)
+    eng.load_params(hf.fill_params(310, H, A))
+    logits, values = eng.forward(hf.hf_bytes(301, (8, 4, 84, 84)))
+    np.testing.assert_allclose(logits, golden[f"g3_H{H}_A{A}_logits"], atol=3e-2)
+    np.testing.assert_allclose(values, golden[f"g3_H{H}_A{A}_values"], atol=3e-2)
+    eng.close()
+
+
+def test_forward_ragged_batch_vs_oracle(pkg):
+    H, A, n = 64, 5, 37  # n not a multiple of any tile
+    params = hf.fill_params(77, H, A)
+    obs = hf.hf_bytes(78, (n, 4, 84, 84))
+    eng = pkg.Engine(n, 1, A, H, precision=pkg.FP32)
+    eng.load_params(params)
+    logits, values = eng.forward(obs)
+    wl, wv = orc.net_forward(params, H, A, obs)
+    np.testing.assert_allclose(logits, wl, atol=1e-4)
+    np.testing.assert_allclose(values, wv, atol=1e-4)
+    eng.close()
+
+
+# ------------------------------------------------------------------ full update vs the reference's train()
+def _g4_inputs(golden):
+    N, A = 64, 4
+    return (hf.hf_bytes(401, (N, 4, 84, 84)), (hf.hf_u32(402, N) % np.uint32(A)).astype(np.int64), golden["g4_old_logp"],
+            hf.hf_range(404, (N,), -1, 1), hf.hf_range(405, (N,), -1, 1),
+            (hf.hf_unit(406, N) >= np.float32(0.1)).astype(np.uint8))
+
+
+@pytest.mark.parametrize("name,epochs,M", [("a", 1, 1), ("b", 2, 4)])
+def test_train_g4_fp32(pkg, golden, name, epochs, M):
+    H, A, N = 32, 4, 64
+    obs, actions, old_lp, adv, ret, masks = _g4_inputs(golden)
+    eng = pkg.Engine(8, 8, A, H, precision=pkg.FP32)  # E*T = 64 samples
+    eng.load_params(hf.fill_params(410, H, A))
+    eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+    m = eng.train(2.5e-4, epochs, M)
+    s = f"g4{name}_"
+    B = N // M
+    np.testing.assert_allclose(m["loss"], golden[s + "loss"], atol=1e-4)
+    np.testing.assert_allclose(m["grad_norm"], golden[s + "grad_norm"], rtol=1e-4)
+    for ours, ref in (("total_losses", "total_losses"), ("ratio", "ratio"), ("entropies", "entropies"),
+                      ("value_losses", "value_losses"), ("clipped_losses", "clipped")):
+        np.testing.assert_allclose(eng.read_train_metric(ours, epochs, M, B), golden[s + ref], atol=1e-4,
+                                   err_msg=ours)
+    p = eng.export_params()
+    g = eng.export_grads()
+    offs = orc.param_offsets(H, A)
+    shapes = hf.param_shapes(H, A)
+    for k in range(12):
+        pk = p[offs[k]:offs[k + 1]].astype(np.float64)
+        gk = g[offs[k]:offs[k + 1]].astype(np.float64)
+        idx = (hf.hf_u32(499, 64) % np.uint32(pk.size)).astype(np.int64)
+        np.testing.assert_allclose(pk[idx], golden[s + "param_samples"][k], atol=1e-4, err_msg=f"param {k}")
+        np.testing.assert_allclose(gk[idx], golden[s + "grad_samples"][k], atol=2e-5, rtol=2e-3, err_msg=f"grad {k}")
+        np.testing.assert_allclose((gk * gk).sum(), golden[s + "grad_sums"][k][1], rtol=5e-3, atol=1e-9)
+    for k in (0, 1, 3, 5, 7, 8, 9, 10, 11):
+        np.testing.assert_allclose(p[offs[k]:offs[k + 1]].reshape(shapes[k]), golden[s + f"param{k}"], atol=1e-4)
+    eng.close()
+
+
+@pytest.mark.parametrize("prec,H,A,N,M", [("fp32", 512, 6, 96, 2), ("fp32", 64, 4, 40, 1), ("bf16", 512, 4, 96, 2)])
+def test_train_vs_oracle(pkg, prec, H, A, N, M):
+    params = hf.fill_params(510, H, A)
+    obs = hf.hf_bytes(511, (N, 4, 84, 84))
+    actions = (hf.hf_u32(512, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(513, (N, A), -1, 1))
+    adv = hf.hf_range(514, (N,), -1, 1)
+    ret = hf.hf_range(515, (N,), -1, 1)
+    masks = (hf.hf_unit(516, N) >= np.float32(0.1)).astype(np.uint8)
+    eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.FP32 if prec == "fp32" else pkg.BF16)
+    eng.load_params(params)
+    eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+    m = eng.train(2.5e-4, 2, M)
+    w = orc.train(params, H, A, obs, actions, old_lp, adv, ret, masks, 2, M)
+    tol = 1e-4 if prec == "fp32" else 3e-2  # bf16: documented looser bound
+    np.testing.assert_allclose(m["loss"], w["loss"], atol=tol)
+    np.testing.assert_allclose(m["grad_norm"], w["grad_norm"], rtol=1e-3 if prec == "fp32" else 5e-2)
+    if prec == "fp32":
+        np.testing.assert_allclose(eng.export_params(), w["params"], atol=1e-4)
+        g, wg = eng.export_grads(), w["last_grads"]
+        np.testing.assert_allclose(g, wg, atol=1e-5 + 2e-3 * np.abs(wg).max())
+    eng.close()
+
+
+# ------------------------------------------------------------------ the whole rollout protocol
+def _run_rollouts(pkg, E, T, A, H, rollouts, kind):
+    params = hf.fill_params(610, H, A)
+    eng = pkg.Engine(E, T, A, H, precision=pkg.FP32)
+    eng.load_params(params)
+    lut = ((np.arange(256) * 5 + 1) % 256).astype(np.uint8)
+    if kind == "raw":
+        eng.set_gray_lut(lut)
+    rng = np.random.default_rng(3)
+    obs_ref = np.zeros((E, 4, 84, 84), np.uint8)
+    start = np.ones(E, np.uint8)
+    rewards = np.zeros(E, np.float32)
+    for ro in range(rollouts):
+        rec = dict(obs=[], act=[], rew=[], term=[], trunc=[], start=[], noise=[])
+        for t in range(T):
+            noise = rng.exponential(size=(E, A)).astype(np.float32)
+            actions = eng.act(noise).copy()
+            np.testing.assert_array_equal(eng.read_batch("current_obs"), obs_ref)
+            rec["obs"].append(obs_ref.copy())
+            rec["act"].append(actions)
+            rec["noise"].append(noise)
+            if kind == "raw":
+                raw = hf.hf_bytes(2000 + ro * T + t, (E, 2, 210, 160))
+                frames = orc.preprocess(raw, lut)
+            else:
+                frames = hf.hf_bytes(2000 + ro * T + t, (E, 84, 84))
+            u = rng.random(E)
+            term = ((u < 0.15) & (start == 0)).astype(np.uint8)
+            trunc = ((u >= 0.15) & (u < 0.2) & (start == 0)).astype(np.uint8)
+            rewards = np.where(start == 1, rewards, rng.integers(-3, 4, E)).astype(np.float32)  # stale on start
+            if kind == "raw":
+                eng.push_frames(raw, start, kind=pkg.FRAMES_RAW_PAIR)
+                eng.record_step(rewards, term, trunc, start)
+            else:
+                eng.step(frames, rewards, term, trunc, start)
+            rec["rew"].append(rewards.copy()); rec["term"].append(term); rec["trunc"].append(trunc)
+            rec["start"].append(start.copy())
+            obs_ref = orc.update_observations(obs_ref, frames, start)
+            start = (term | trunc).astype(np.uint8)
+        eng.finish_rollout(rng.exponential(size=(E, A)).astype(np.float32))
+        yield eng, params, rec, obs_ref
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["84", "raw"])
+def test_rollout_protocol_vs_oracle(pkg, kind):
+    E, T, A, H = 6, 9, 6, 64
+    for eng, params, rec, obs_after in _run_rollouts(pkg, E, T, A, H, 2, kind):
+        em = lambda k: np.stack(rec[k], 1)  # [T][E] lists -> env-major [E,T]
+        b = {k: eng.read_batch(k) for k in pkg.FIELDS if k != "current_obs"}
+        # byte / flag / index planes: bit-exact
+        np.testing.assert_array_equal(b["observations"], em("obs"))
+        np.testing.assert_array_equal(b["terminals"], em("term"))
+        np.testing.assert_array_equal(b["truncations"], em("trunc"))
+        np.testing.assert_array_equal(b["masks"], 1 - em("start"))
+        np.testing.assert_array_equal(b["rewards"], np.clip(em("rew"), -1, 1))  # clamped in place (buffer.cc:67)
+        # network outputs vs oracle forward on the same observations
+        wl, wv = orc.net_forward(params, H, A, em("obs").reshape(E * T, 4, 84, 84))
+        np.testing.assert_allclose(b["logits"].reshape(E * T, A), wl, atol=1e-4)
+        np.testing.assert_allclose(b["values"].ravel(), wv, atol=1e-4)
+        _, nv = orc.net_forward(params, H, A, obs_after)
+        np.testing.assert_allclose(b["next_values"], nv, atol=1e-4)
+        # sampled actions: bit-exact given OUR logits and the same noise (tie-margin free definition)
+        want = orc.sample(orc.softmax(b["logits"].reshape(E * T, A)), em("noise").reshape(E * T, A))
+        np.testing.assert_array_equal(b["actions"].ravel(), want)
+        np.testing.assert_array_equal(b["actions"], em("act"))
+        # GAE / returns / log-probs from OUR stored values: same fp32 op order -> tight
+        o = orc.buffer_get(em("rew"), b["values"], b["next_values"], em("term"), em("trunc"), em("start"))
+        np.testing.assert_allclose(b["advantages"], o["advantages"], atol=1e-6)
+        np.testing.assert_allclose(b["returns"], o["returns"], atol=1e-6)
+        np.testing.assert_allclose(b["log_probs"].reshape(E * T, A), orc.log_softmax(b["logits"].reshape(E * T, A)),
+                                   atol=2e-6)
+        # and the update on that batch equals the oracle's update on the same batch
+        m = eng.train(1e-3, 1, 3)
+        w = orc.train(params, H, A, b["observations"].reshape(E * T, 4, 84, 84), b["actions"].ravel(),
+                      b["log_probs"].reshape(E * T, A), b["advantages"].ravel(), b["returns"].ravel(),
+                      b["masks"].ravel(), 1, 3, lr=1e-3)
+        np.testing.assert_allclose(m["loss"], w["loss"], atol=1e-4)
+        np.testing.assert_allclose(m["grad_norm"], w["grad_norm"], rtol=1e-3)
+        new = eng.export_params()
+        np.testing.assert_allclose(new, w["params"], atol=1e-4)
+        params[:] = new  # the next rollout acts with the updated weights on both sides
+
+
+def test_buffer_not_full_and_bad_minibatch_errors(pkg):
+    eng = pkg.Engine(4, 4, 4, 32)
+    with pytest.raises(pkg.AleppoError, match="Buffer is not full"):
+        eng.finish_rollout()
+    eng.set_batch(np.zeros((16, 4, 84, 84), np.uint8), np.zeros(16, np.int64), np.zeros((16, 4), np.float32),
+                  np.zeros(16), np.zeros(16), np.ones(16, np.uint8))
+    with pytest.raises(pkg.AleppoError, match="divisible by num_mini_batches"):
+        eng.train(1e-3, 1, 3)
+    eng.close()
+
+
+def test_builtin_rng_is_deterministic_and_roughly_uniform(pkg):
+    E, A = 512, 4
+    counts = np.zeros(A)
+    seqs = []
+    for rep in range(2):
+        eng = pkg.Engine(E, 2, A, 32, seed=123)
+        eng.load_params(np.zeros(eng.param_count, np.float32))  # all-zero net -> uniform policy
+        a0 = eng.act().copy()
+        eng.step(np.zeros((E, 84, 84), np.uint8), np.zeros(E), np.zeros(E), np.zeros(E), np.ones(E))
+        a1 = eng.act().copy()
+        seqs.append(np.concatenate([a0, a1]))
+        eng.close()
+    np.testing.assert_array_equal(seqs[0], seqs[1])
+    for k in range(A):
+        counts[k] = (seqs[0] == k).sum()
+    assert counts.min() > 0.15 * 2 * E and (seqs[0][:E] != seqs[0][E:]).any()
