@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(typename AL::P ap, typenam
 // grid.z = split-K slice; each slice writes an fp32 partial slab [z][M][N] that
 // reduce_slabs_kernel sums in fixed order (deterministic; no atomics).
 // BIAS: n-tile 0 also emits column sums of A (the bias gradient) into bias_slab [z][M].
+// out_scale multiplies the weight slab (conv1: the 1/255 input scaling that forward folds into its epilogue).
 // ------------------------------------------------------------------------------------------------
 template <class T> __device__ __forceinline__ u32x4 lds_gather_k(const T *base, int stride_elems);
 template <> __device__ __forceinline__ u32x4 lds_gather_k<float>(const float *b, int s) {
@@ -345,7 +346,8 @@ template <> __device__ __forceinline__ u32x4 lds_gather_k<bf16>(const bf16 *b, i
 
 template <class T, class AL, class BL, int BM, int BN, int WM, int WN, bool BIAS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typename BL::P bp, float *slab,
-                                                       float *bias_slab, int M, int N, int Ktot, int kchunk) {
+                                                       float *bias_slab, int M, int N, int Ktot, int kchunk,
+                                                       float out_scale) {
   using AT = Atom<T>;
   constexpr int VE = AT::VE, KP = AT::KT; // pixels per stage
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
         for (int j = 0; j < NI; ++j) {
           const int n = n0 + wn * WTN + j * 16 + fr;
           if (n < N)
-            out[(long)m * N + n] = acc[i][j][r];
+            out[(long)m * N + n] = acc[i][j][r] * out_scale;
         }
       }
     }

@@ -186,16 +186,20 @@ void launch_infer_head(hipStream_t s, const float *h, const float *Wh, const flo
 // Rollout scalars are time-major [T][E] so each wave reads 64 consecutive environments per slot
 // (coalesced); one thread owns one environment and scans t = T-1..0.  Outputs are the env-major
 // (n = e*T + t) training arrays the minibatch slices index (Q1, Q5).  The float op order of
-// gae.cc:61-66 is pinned with __f*_rn so no fma contraction changes the rounding.
+// gae.cc:61-66 is pinned (fp contract off) so no fma contraction changes the rounding.
 // ================================================================================================
 __device__ __forceinline__ float gae_step(float r, float v, float nv, float last, float gamma, float gl, bool st,
                                           bool te, bool tr) {
-  const float boot = __fsub_rn(__fadd_rn(r, __fmul_rn(gamma, nv)), v); // (r + g*nv) - v
-  float a = __fadd_rn(boot, __fmul_rn(gl, last));                      // running,   gae.cc:61-63
+#pragma clang fp contract(off) // keep the reference's separate mul / add roundings (no fma)
+  const float t1 = gamma * nv;
+  const float t2 = r + t1;
+  const float boot = t2 - v;                                           // (r + g*nv) - v
+  const float t3 = gl * last;
+  float a = boot + t3;                                                 // running,   gae.cc:61-63
   if (st)
     a = 0.f;                                                           // start,     gae.cc:68-69
   if (te)
-    a = __fsub_rn(r, v);                                               // terminal,  gae.cc:64,70-71
+    a = r - v;                                                         // terminal,  gae.cc:64,70-71
   if (tr)
     a = boot;                                                          // truncated, gae.cc:65-66,72-73
   return a;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E)
     return;
-  const float gl = __fmul_rn(gamma, lambda);
+  const float gl = gamma * lambda;
   float last = 0.f, nv = values_tm[(size_t)T * E + e];
   for (int t = T - 1; t >= 0; --t) {
     float *rp = reinterpret_cast<float *>(rec + (size_t)t * rb);
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
     const float a = gae_step(r, v, nv, last, gamma, gl, st, te, tr);
     const size_t n = (size_t)e * T + t;
     adv_n[n] = a;
-    ret_n[n] = __fadd_rn(a, v); // buffer.cc:70-71
+    ret_n[n] = a + v;           // buffer.cc:70-71
     mask_n[n] = st ? 0 : 1;     // buffer.cc:74
     act_n[n] = actions_tm[(size_t)t * E + e];
     const float *z = logits_tm + ((size_t)t * E + e) * A;
@@ -254,7 +258,7 @@ __global__ void gae_op_kernel(float *adv, const float *r, const float *v, const 
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E)
     return;
-  const float gl = __fmul_rn(gamma, lambda);
+  const float gl = gamma * lambda;
   float last = 0.f, nv = nv0[e];
   for (int t = T - 1; t >= 0; --t) {
     const size_t k = (size_t)e * T + t;
@@ -841,8 +845,11 @@ __global__ void rgb_to_gray_kernel(const float *in, float *out) {
   if (p >= FRAME_PIX)
     return;
   const float *s = in + (size_t)n * 3 * FRAME_PIX + p;
-  out[(size_t)n * FRAME_PIX + p] =
-      __fadd_rn(__fadd_rn(__fmul_rn(s[0], 0.2125f), __fmul_rn(s[FRAME_PIX], 0.7154f)), __fmul_rn(s[2 * FRAME_PIX], 0.0721f));
+  {
+#pragma clang fp contract(off)
+    const float a = s[0] * 0.2125f, b = s[FRAME_PIX] * 0.7154f, c = s[2 * FRAME_PIX] * 0.0721f;
+    out[(size_t)n * FRAME_PIX + p] = (a + b) + c;
+  }
 }
 void launch_rgb_to_gray(hipStream_t s, const float *in, float *out, long n) {
   hipLaunchKernelGGL(rgb_to_gray_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)n), dim3(256), 0, s, in, out);
