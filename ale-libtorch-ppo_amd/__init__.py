@@ -47,7 +47,7 @@ EXPORTS = [
     "aleppo_read_train_metric", "aleppo_set_batch", "aleppo_read_batch", "aleppo_forward", "aleppo_comm_unique_id",
     "aleppo_comm_init", "aleppo_gae", "aleppo_vision_resize_area", "aleppo_vision_rgb_to_gray", "aleppo_preprocess",
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
-    "aleppo_profile_reset", "aleppo_synchronize",
+    "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option",
 ]
 
 
@@ -361,6 +361,10 @@ class Engine:
         n = C.c_int64()
         self._c(lib().aleppo_profile_read(self._ctx, KERNEL_CLASSES[name], C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def set_generic_conv(self, on):
+        """A/B switch: run bf16 convolutions on the generic gather-GEMM kernels (process-wide)."""
+        self._c(lib().aleppo_set_option(self._ctx, 0, int(on)))
 
     def synchronize(self):
         self._c(lib().aleppo_synchronize(self._ctx))

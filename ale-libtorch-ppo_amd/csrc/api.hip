@@ -663,15 +663,15 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
       prof_end(c, ALEPPO_K_FC_DGRAD);
       prof_begin(c, ALEPPO_K_FC_WGRAD);
-      const int Sfc = fc_wgrad(s, prec, c->dh, c->a3, sWfc, sBfc, B, H);
+      (void)sWfc;
+      (void)sBfc;
+      fc_wgrad(s, prec, c->dh, c->a3, c->G + L.off[P_WFC], c->G + L.off[P_BFC], B, H); // single slice -> G directly
       prof_end(c, ALEPPO_K_FC_WGRAD);
       prof_begin(c, ALEPPO_K_REDUCE);
       {
-        const ReduceSeg segs[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
-                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]},
-                                   {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
-                                   {sBfc, Sfc, (long)H, (long)L.off[P_BFC]}};
-        launch_reduce_slabs(s, segs, 4, c->G);
+        const ReduceSeg segs[2] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
+                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]}};
+        launch_reduce_slabs(s, segs, 2, c->G);
       }
       prof_end(c, ALEPPO_K_REDUCE);
       if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs
@@ -921,6 +921,14 @@ extern "C" int aleppo_comm_init(aleppo_ctx *c, const uint8_t id[ALEPPO_UNIQUE_ID
 }
 
 // ------------------------------------------------------------------ profiling
+extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
+  CHECK_CTX(c);
+  if (option != ALEPPO_OPT_GENERIC_CONV)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  set_patch_kernels(value == 0);
+  return ALEPPO_OK;
+}
 extern "C" int aleppo_profile_enable(aleppo_ctx *c, int on) {
   CHECK_CTX(c);
   c->prof_on = on != 0;

@@ -17,7 +17,7 @@ constexpr int A3_PIX = 49, A3_C = 64;       // conv3 out 7x7x64
 constexpr int FC_IN = 3136;
 constexpr int MAX_ACTIONS = 18;
 // split-K slice caps of the wgrad slabs (gemm_launch.hip) and of the head kernel's partial slabs
-constexpr int MAXS_C1 = 256, MAXS_C2 = 128, MAXS_C3 = 64, MAXS_FC = 4, MAXS_HEAD = 256;
+constexpr int MAXS_C1 = 256, MAXS_C2 = 256, MAXS_C3 = 256, MAXS_FC = 4, MAXS_HEAD = 256;
 
 // ---- internal flat parameter layout (fp32 master, Adam moments, gradient share it) ----
 // order chosen so that what backward finishes FIRST is at the FRONT: bucket 0 = heads + fc can be
@@ -198,6 +198,20 @@ int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float 
 int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *slab_w, float *slab_b, long ns);
 int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *slab_w,
                 float *slab_b, long ns);
+
+// ------------------------------------------------------------------ sample-stationary bf16 conv kernels (conv_patch_launch.hip)
+bool use_patch_kernels(); // false when ALEPPO_GENERIC_CONV=1
+void set_patch_kernels(bool on);
+void patch_conv1_fwd(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
+                     long ns);
+void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns);
+void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns);
+void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns);
+void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns);
+int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
+                      long ns);
+int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns);
+int patch_conv3_wgrad(hipStream_t s, const void *dz3, const void *a2, float *sw, float *sb, long ns);
 
 } // namespace aleppo
 

@@ -1,0 +1,473 @@
+// conv_patch.hpp - sample-stationary bf16 convolution kernels for gfx950 (the performance path).
+//
+// The generic gather-GEMMs of gemm.hpp re-stage an im2col tile per 64-deep k-step and pay a full
+// prologue per 128-row tile - fine for parity (fp32), wasteful for these skinny problems (N = 32/64
+// output channels, K = 256..576).  Here each workgroup is PERSISTENT (one per CU, 8 waves) and streams
+// samples: the input patch of SB samples (<= 62 KB as bf16) is staged ONCE in LDS (conv1: u8 -> bf16
+// widened once instead of once per 8x8 window, 4x less conversion work), the layer's weights live in
+// REGISTERS for the whole kernel (each wave owns two 16-channel atoms = 64..144 VGPRs), and the MFMA
+// operands are read from the patch with im2col addressing (base + immediate offset per k-step).
+// Next group's global loads are in flight during the current group's MFMAs (register prefetch, LDS double
+// buffer, one barrier per group).
+//
+//   conv_patch_kernel<L>  forward (conv1/2/3) and dgrad (conv3, conv2 by parity class):
+//        D[oc][pixel] = sum_k W[oc][k] * gather(patch)[pixel][k]        (A = weights, B = patch)
+//   conv_wgrad_patch_kernel<L>: dW[oc][j] += sum_pixel dY[pixel][oc] * im2col(X)[pixel][j]
+//        accumulators stay in registers across ALL samples of the workgroup (one slab per workgroup);
+//        both operands are k(=pixel)-outer in LDS and read with ds_read_b64_tr_b16.
+#pragma once
+#include "gemm.hpp"
+
+namespace aleppo {
+
+enum PatchMode { PM_FWD = 0, PM_DGRAD = 1 };
+
+// ---- layer descriptors ---------------------------------------------------------------------------
+// forward: NHWC input [IH][IW][C], KHxKW window, stride S -> PIX = OHxOW output pixels, OUTC channels
+// conv1 works on HALF samples (output rows 0-9 / 10-19 <- input rows 0-43 / 40-83) so that two LDS buffers
+// of the widened patch stay small (2 x 29.6 KB): GPS = groups per sample, GSTRIDE = source elements between
+// the starts of consecutive groups of one sample.
+struct LConv1Fwd {
+  static constexpr int MODE = PM_FWD;
+  using InT = uint8_t;
+  static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4;
+};
+struct LConv2Fwd {
+  static constexpr int MODE = PM_FWD;
+  using InT = bf16;
+  static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OUTC = 64, KS = 16,
+                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
+};
+struct LConv3Fwd {
+  static constexpr int MODE = PM_FWD;
+  using InT = bf16;
+  static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
+                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
+};
+// dgrad: input = dY [OH][OW][OCK], output pixel grid PH x PW, taps TH x TW, source pixel (y-dy, x-dx)
+struct LConv3Dgrad {
+  static constexpr int MODE = PM_DGRAD;
+  using InT = bf16;
+  static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
+                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
+};
+struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
+  static constexpr int MODE = PM_DGRAD;
+  using InT = bf16;
+  static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
+                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0;
+};
+
+struct PatchParams {
+  const void *in;     // activations / dY (bf16) or packed u8 stacks
+  const bf16 *w;      // [CLASSES][OUTC][32*KS]
+  const float *bias;  // fwd
+  const bf16 *act;    // dgrad: activation whose ReLU gates the result (same indexing as out)
+  bf16 *out;
+  long ns;            // samples
+  SampleMap map;      // conv1 only: where sample n's packed stack lives (units: u32 pixels)
+  float scale;        // fwd epilogue: v*scale + bias
+};
+
+__device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 lo = {(bf16)a, (bf16)b}, hi = {(bf16)c, (bf16)d};
+  return u32x2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+
+template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(PatchParams P) {
+  using InT = typename L::InT;
+  constexpr bool U8 = sizeof(InT) == 1;
+  constexpr int K = 32 * L::KS;
+  constexpr int PATCH = L::IN_ELEMS;                         // bf16 elements per sample in LDS
+  constexpr int BUF_ELEMS = (L::SB * PATCH + 63) / 64 * 64;  // per buffer
+  constexpr int SRC_VECS = L::SB * PATCH * (int)sizeof(InT) / 16; // 16-byte source vectors per group
+  constexpr int NV = (SRC_VECS + 511) / 512;
+  constexpr int NL = 8 / L::OG;                              // pixel lanes (waves sharing an oc group)
+  constexpr int NATOM = (L::SB * L::PIX + 15) / 16;
+  static_assert((L::SB * PATCH * (int)sizeof(InT)) % 16 == 0, "group size");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  bf16 *sbuf = reinterpret_cast<bf16 *>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int og = wave % L::OG, pl = wave / L::OG;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- weights of this wave's two 16-channel atoms -> registers (A operand: row = fr, k = 32ks + 8fg)
+  const int wrow0 = (L::CLASSES > 1 ? og * L::OUTC : og * 32);
+  u32x4 W[2][L::KS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int ks = 0; ks < L::KS; ++ks)
+      W[a][ks] = *reinterpret_cast<const u32x4 *>(P.w + (long)(wrow0 + a * 16 + fr) * K + ks * 32 + fg * 8);
+  const int oc0 = (L::CLASSES > 1 ? 0 : og * 32) + fg * 4; // first of this lane's 4 output channels (atom 0)
+  float bias_r[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      bias_r[a][r] = (L::MODE == PM_FWD) ? P.bias[oc0 + a * 16 + r] : 0.f;
+
+  // a "unit" is a sample (GPS == 1) or a half sample (conv1); a group is SB consecutive units
+  const long nunits = P.ns * L::GPS;
+  const long ngroups = (nunits + L::SB - 1) / L::SB;
+  u32x4 R[NV];
+  auto gload = [&](long grp) {
+    const long n0 = grp * L::SB;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + 512 * i;
+      R[i] = zero16();
+      if (v < SRC_VECS && grp < ngroups) {
+        if constexpr (U8) { // SB == 1: one half of a packed stack per group, located through the slot map
+          const long n = n0 / L::GPS + P.map.n0;
+          const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base; // u32 pixels
+          R[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.in) + off * 4 +
+                                                 (n0 % L::GPS) * (long)L::GSTRIDE)[v];
+        } else {
+          const int s = v / (PATCH / 8);
+          if (n0 + s < nunits)
+            R[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.in) + n0 * PATCH)[v];
+        }
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+    bf16 *dst = sbuf + (size_t)buf * BUF_ELEMS;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + 512 * i;
+      if (v < SRC_VECS) {
+        if constexpr (U8) { // 16 bytes -> 16 bf16 (exact), two LDS vectors
+          auto pk = [](uint32_t lo, uint32_t hi) {
+            return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+          };
+          u32x4 o0, o1;
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t w0 = R[i][2 * d], w1 = R[i][2 * d + 1];
+            const u32x4 o = {pk(w0 & 255u, (w0 >> 8) & 255u), pk((w0 >> 16) & 255u, w0 >> 24),
+                             pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
+            if (d == 0)
+              o0 = o;
+            else
+              o1 = o;
+          }
+          reinterpret_cast<u32x4 *>(dst)[2 * v] = o0;
+          reinterpret_cast<u32x4 *>(dst)[2 * v + 1] = o1;
+        } else {
+          reinterpret_cast<u32x4 *>(dst)[v] = R[i];
+        }
+      }
+    }
+  };
+
+  long grp = blockIdx.x;
+  gload(grp);
+  swrite(0);
+  gload(grp + gridDim.x);
+  __syncthreads();
+  for (int it = 0; grp < ngroups; grp += gridDim.x, ++it) {
+    const bf16 *pb = sbuf + (size_t)(it & 1) * BUF_ELEMS;
+    const long n0 = grp * L::SB; // first unit of this group; unit u covers output pixels [u*PIX, (u+1)*PIX)
+    const int count = (int)min((long)L::SB, nunits - n0);
+    for (int atom = pl; atom < NATOM; atom += NL) {
+      const int q = atom * 16 + fr;
+      const bool qok = q < count * L::PIX;
+      const int s = min(q / L::PIX, L::SB - 1), p = q - (q / L::PIX) * L::PIX;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      long out_off;
+      if constexpr (L::MODE == PM_FWD) {
+        const int oy = p / L::OW, ox = p - oy * L::OW;
+        const int base = qok ? s * PATCH + ((oy * L::S) * L::IW + ox * L::S) * L::C + fg * 8 : fg * 8;
+        constexpr int SEG = L::KW * L::C;
+#pragma unroll
+        for (int ks = 0; ks < L::KS; ++ks) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int koff = ((ks * 32) / SEG) * (L::IW * L::C) + (ks * 32) % SEG;
+          const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
+          Atom<bf16>::mma(W[0][ks], b, acc0);
+          Atom<bf16>::mma(W[1][ks], b, acc1);
+        }
+        out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
+      } else {
+        const int y = p / L::PW, x = p - y * L::PW;
+        const int base = s * PATCH + (y * L::OW + x) * L::OCK + fg * 8;
+        constexpr int KPT = L::OCK / 32; // k-steps per tap
+#pragma unroll
+        for (int ks = 0; ks < L::KS; ++ks) {
+          const int tap = ks / KPT, dy = tap / L::TW, dx = tap - dy * L::TW;
+          const int sy = y - dy, sx = x - dx;
+          const bool ok = qok && sy >= 0 && sy < L::OH && sx >= 0 && sx < L::OW;
+          const int off = base - (dy * L::OW + dx) * L::OCK + (ks % KPT) * 32;
+          u32x4 b = zero16();
+          if (ok)
+            b = *reinterpret_cast<const u32x4 *>(pb + off);
+          Atom<bf16>::mma(W[0][ks], b, acc0);
+          Atom<bf16>::mma(W[1][ks], b, acc1);
+        }
+        if constexpr (L::CLASSES > 1) { // conv2 dgrad: pixel (2y+py, 2x+px) of the 20x20x32 tensor
+          const int py = og >> 1, px = og & 1;
+          out_off = (((n0 + s) * 20 + 2 * y + py) * 20 + 2 * x + px) * (long)L::OUTC + oc0;
+        } else {
+          out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
+        }
+      }
+      if (qok) {
+        if constexpr (L::MODE == PM_FWD) {
+          float v0[4], v1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v0[r] = fmaxf(acc0[r] * P.scale + bias_r[0][r], 0.f);
+            v1[r] = fmaxf(acc1[r] * P.scale + bias_r[1][r], 0.f);
+          }
+          *reinterpret_cast<u32x2 *>(P.out + out_off) = pack4_bf16(v0[0], v0[1], v0[2], v0[3]);
+          *reinterpret_cast<u32x2 *>(P.out + out_off + 16) = pack4_bf16(v1[0], v1[1], v1[2], v1[3]);
+        } else {
+          const u32x2 m0 = *reinterpret_cast<const u32x2 *>(P.act + out_off);
+          const u32x2 m1 = *reinterpret_cast<const u32x2 *>(P.act + out_off + 16);
+          auto gate = [](uint32_t w, int hi, float v) { // ReLU gate on the stored bf16 activation
+            const float a = bf16_bits_to_f32(hi ? (w >> 16) : (w & 0xFFFFu));
+            return a > 0.f ? v : 0.f;
+          };
+          *reinterpret_cast<u32x2 *>(P.out + out_off) =
+              pack4_bf16(gate(m0[0], 0, acc0[0]), gate(m0[0], 1, acc0[1]), gate(m0[1], 0, acc0[2]),
+                         gate(m0[1], 1, acc0[3]));
+          *reinterpret_cast<u32x2 *>(P.out + out_off + 16) =
+              pack4_bf16(gate(m1[0], 0, acc1[0]), gate(m1[0], 1, acc1[1]), gate(m1[1], 0, acc1[2]),
+                         gate(m1[1], 1, acc1[3]));
+        }
+      }
+    }
+    swrite((it + 1) & 1);
+    gload(grp + 2 * (long)gridDim.x);
+    __syncthreads();
+  }
+}
+
+template <class L> constexpr size_t conv_patch_smem() {
+  return (size_t)2 * ((L::SB * L::IN_ELEMS + 63) / 64 * 64) * 2;
+}
+
+// ================================================================================================
+// wgrad: dW[oc][j] = sum over (sample, pixel) of dY[pixel][oc] * im2col(X)[pixel][j]
+// ================================================================================================
+struct LConv1Wgrad { // half-sample units like LConv1Fwd
+  using InT = uint8_t;
+  static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OC = 32, NJ = 256,
+                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4; // wave: 2 oc x 2 of 16 j atoms
+};
+struct LConv2Wgrad {
+  using InT = bf16;
+  static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OC = 64, NJ = 512, SB = 1,
+                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0; // wave: all 4 oc atoms x 4 of the 32 j atoms
+};
+struct LConv3Wgrad {
+  using InT = bf16;
+  static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OC = 64, NJ = 576, SB = 4,
+                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0; // wave: 2 of 4 oc atoms x 9 of the 36 j atoms
+};
+
+struct WgradParams {
+  const void *x;    // layer input (bf16 NHWC, or packed u8 stacks)
+  const bf16 *dy;   // [ns][PIX][OC]
+  float *slab_w;    // [gridDim.x][OC][NJ]
+  float *slab_b;    // [gridDim.x][OC]
+  long ns;
+  SampleMap map;
+  float scale;
+};
+
+template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(WgradParams P) {
+  using InT = typename L::InT;
+  constexpr bool U8 = sizeof(InT) == 1;
+  constexpr int PATCH = L::IN_ELEMS;
+  constexpr int KPIX = L::SB * L::PIX;            // reduction length per group
+  constexpr int KS = (KPIX + 31) / 32;            // atom-k steps per group (tail rows of dY are zero)
+  constexpr int DYS = L::OC + 16;                 // dY tile row stride: (OC/2+8) dwords = 8 (mod 16)
+  constexpr int X_ELEMS = (L::SB * PATCH + 63) / 64 * 64;
+  constexpr int DY_ELEMS = KS * 32 * DYS;
+  constexpr int BUF_ELEMS = X_ELEMS + DY_ELEMS;
+  constexpr int XV = L::SB * PATCH * (int)sizeof(InT) / 16, NXV = (XV + 511) / 512;
+  constexpr int DV = KPIX * L::OC / 8, NDV = (DV + 511) / 512; // dY source vectors (8 bf16)
+  constexpr int VPR = L::OC / 8;                  // dY vectors per pixel row
+  constexpr int WN = 8 / L::WM;
+  constexpr int SEG = L::KW * L::C;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  bf16 *sbuf = reinterpret_cast<bf16 *>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % L::WM, wn = wave / L::WM;
+  const int li = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[L::MI][L::NI];
+#pragma unroll
+  for (int i = 0; i < L::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < L::NI; ++j)
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // this thread's 8 fixed channels (tid % VPR)
+
+  // B-operand (im2col) element offsets of this lane: for tr-read r of k-step ks the lane supplies the
+  // address of pixel (32ks + 16r + 4lg + (li>>2)), columns j0 + 4(li&3)..+3.  Pixel -> patch offset
+  // depends only on (ks, r): precomputed once (same for every group).
+  int pixoff[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int q = ks * 32 + r * 16 + 4 * lg + (li >> 2);
+      q = min(q, KPIX - 1); // tail pixels: dY rows are zero, any finite in-range patch data will do
+      const int s = q / L::PIX, p = q - s * L::PIX, oy = p / L::OW, ox = p - oy * L::OW;
+      pixoff[ks][r] = s * PATCH + ((oy * L::S) * L::IW + ox * L::S) * L::C;
+    }
+  int joff[L::NI]; // column part: j = 16*(atom) + 4(li&3) -> (kh, inner)
+#pragma unroll
+  for (int j = 0; j < L::NI; ++j) {
+    const int jj = (wn * L::NI + j) * 16 + 4 * (li & 3);
+    joff[j] = (jj / SEG) * (L::IW * L::C) + jj % SEG;
+  }
+
+  const long nunits = P.ns * L::GPS; // unit = sample or half sample; dY of unit u = rows [u*PIX, (u+1)*PIX)
+  const long ngroups = (nunits + L::SB - 1) / L::SB;
+  u32x4 RX[NXV], RD[NDV];
+  auto gload = [&](long grp) {
+    const long n0 = grp * L::SB;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int v = tid + 512 * i;
+      RX[i] = zero16();
+      if (v < XV && grp < ngroups) {
+        if constexpr (U8) {
+          const long n = n0 / L::GPS + P.map.n0;
+          const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base;
+          RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.x) + off * 4 +
+                                                  (n0 % L::GPS) * (long)L::GSTRIDE)[v];
+        } else {
+          const int s = v / (PATCH / 8);
+          if (n0 + s < nunits)
+            RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.x) + n0 * PATCH)[v];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int v = tid + 512 * i;
+      RD[i] = zero16();
+      if (v < DV && grp < ngroups) {
+        const int s = (v / VPR) / L::PIX;
+        if (n0 + s < nunits)
+          RD[i] = reinterpret_cast<const u32x4 *>(P.dy + n0 * (long)(L::PIX * L::OC))[v];
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+    bf16 *dx = sbuf + (size_t)buf * BUF_ELEMS, *dd = dx + X_ELEMS;
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int v = tid + 512 * i;
+      if (v < XV) {
+        if constexpr (U8) {
+          auto pk = [](uint32_t lo, uint32_t hi) {
+            return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+          };
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t w0 = RX[i][2 * d], w1 = RX[i][2 * d + 1];
+            reinterpret_cast<u32x4 *>(dx)[2 * v + d] =
+                u32x4{pk(w0 & 255u, (w0 >> 8) & 255u), pk((w0 >> 16) & 255u, w0 >> 24),
+                      pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
+          }
+        } else {
+          reinterpret_cast<u32x4 *>(dx)[v] = RX[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int v = tid + 512 * i;
+      if (v < DV) {
+        const int row = v / VPR, cv = v - row * VPR;
+        *reinterpret_cast<u32x4 *>(dd + row * DYS + cv * 8) = RD[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { // bias gradient: running column sums of what this thread stages
+          bsum[2 * e] += bf16_bits_to_f32(RD[i][e] & 0xFFFFu);
+          bsum[2 * e + 1] += bf16_bits_to_f32(RD[i][e] >> 16);
+        }
+      }
+    }
+  };
+  // zero the dY tail rows [KPIX, KS*32) of both buffers once (never overwritten afterwards)
+  for (int b = 0; b < 2; ++b)
+    for (int e = tid; e < (KS * 32 - KPIX) * DYS; e += 512)
+      sbuf[(size_t)b * BUF_ELEMS + X_ELEMS + KPIX * DYS + e] = (bf16)0.f;
+
+  long grp = blockIdx.x;
+  gload(grp);
+  swrite(0);
+  gload(grp + gridDim.x);
+  __syncthreads();
+  typedef __attribute__((address_space(3))) bf16x4 *lds4;
+  for (int it = 0; grp < ngroups; grp += gridDim.x, ++it) {
+    const bf16 *px = sbuf + (size_t)(it & 1) * BUF_ELEMS, *pd = px + X_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 fa[L::MI], fb[L::NI];
+#pragma unroll
+      for (int i = 0; i < L::MI; ++i)
+        fa[i] = KFrag<bf16>::read(pd, DYS, ks * 32, (wm * L::MI + i) * 16, lane);
+#pragma unroll
+      for (int j = 0; j < L::NI; ++j) {
+        const u32x2 lo = __builtin_bit_cast(
+            u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(px + pixoff[ks][0] + joff[j])));
+        const u32x2 hi = __builtin_bit_cast(
+            u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(px + pixoff[ks][1] + joff[j])));
+        fb[j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+      for (int i = 0; i < L::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < L::NI; ++j)
+          Atom<bf16>::mma(fa[i], fb[j], acc[i][j]);
+    }
+    swrite((it + 1) & 1);
+    gload(grp + 2 * (long)gridDim.x);
+    __syncthreads();
+  }
+  // ---- one slab per workgroup
+  float *ow = P.slab_w + (long)blockIdx.x * L::OC * L::NJ;
+#pragma unroll
+  for (int i = 0; i < L::MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (wm * L::MI + i) * 16 + lg * 4 + r;
+#pragma unroll
+      for (int j = 0; j < L::NI; ++j)
+        ow[(long)m * L::NJ + (wn * L::NI + j) * 16 + li] = acc[i][j][r] * P.scale;
+    }
+  // bias: threads with equal tid % VPR hold the same 8 channels; ordered LDS reduction (deterministic)
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    red[tid * 8 + e] = bsum[e];
+  __syncthreads();
+  if (tid < L::OC) {
+    const int cv = tid / 8, e = tid % 8;
+    float s = 0.f;
+    for (int t = cv; t < 512; t += VPR)
+      s += red[t * 8 + e];
+    P.slab_b[(long)blockIdx.x * L::OC + tid] = s;
+  }
+}
+
+template <class L> constexpr size_t conv_wgrad_patch_smem() {
+  constexpr int KPIX = L::SB * L::PIX, KS = (KPIX + 31) / 32;
+  return (size_t)2 * (((L::SB * L::IN_ELEMS + 63) / 64 * 64) + KS * 32 * (L::OC + 16)) * 2;
+}
+
+} // namespace aleppo

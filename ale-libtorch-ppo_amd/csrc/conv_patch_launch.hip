@@ -1,0 +1,101 @@
+// conv_patch_launch.hip - launch geometry of the sample-stationary bf16 conv kernels (conv_patch.hpp).
+// Persistent grids: at most one workgroup per CU (the LDS patch buffers are 41..155 KB), 512 threads.
+#include "common.hpp"
+#include "conv_patch.hpp"
+#include <cstdlib>
+
+namespace aleppo {
+
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      n = p.multiProcessorCount;
+    if (n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+static int g_patch = -1;
+bool use_patch_kernels() {
+  if (g_patch < 0) {
+    const char *e = std::getenv("ALEPPO_GENERIC_CONV"); // =1 forces the generic gather-GEMMs (A/B testing)
+    g_patch = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_patch == 1;
+}
+void set_patch_kernels(bool on) { g_patch = on ? 1 : 0; }
+
+template <class K> static void allow_smem(K kernel, size_t bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes);
+}
+
+template <class L> static void launch_patch(hipStream_t s, const PatchParams &P) {
+  static bool once = false;
+  constexpr size_t sm = conv_patch_smem<L>();
+  if (!once) {
+    allow_smem(conv_patch_kernel<L>, sm);
+    once = true;
+  }
+  const long ngroups = (P.ns * L::GPS + L::SB - 1) / L::SB;
+  const int grid = (int)std::min<long>(ngroups, num_cus());
+  hipLaunchKernelGGL((conv_patch_kernel<L>), dim3(grid), dim3(512), sm, s, P);
+}
+
+void patch_conv1_fwd(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
+                     long ns) {
+  PatchParams P{obs, static_cast<const bf16 *>(W1), b1, nullptr, static_cast<bf16 *>(a1), ns, map, 1.0f / 255.0f};
+  launch_patch<LConv1Fwd>(s, P);
+}
+void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
+  PatchParams P{a1, static_cast<const bf16 *>(W2), b2, nullptr, static_cast<bf16 *>(a2), ns, SampleMap{1, 0, 0, 0, 0},
+                1.0f};
+  launch_patch<LConv2Fwd>(s, P);
+}
+void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
+  PatchParams P{a2, static_cast<const bf16 *>(W3), b3, nullptr, static_cast<bf16 *>(a3), ns, SampleMap{1, 0, 0, 0, 0},
+                1.0f};
+  launch_patch<LConv3Fwd>(s, P);
+}
+void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
+  PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),
+                ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
+  launch_patch<LConv3Dgrad>(s, P);
+}
+void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
+  PatchParams P{dz2, static_cast<const bf16 *>(W2d), nullptr, static_cast<const bf16 *>(a1), static_cast<bf16 *>(dz1),
+                ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
+  launch_patch<LConv2Dgrad>(s, P);
+}
+
+template <class L> static int launch_wgrad(hipStream_t s, const WgradParams &P) {
+  static bool once = false;
+  constexpr size_t sm = conv_wgrad_patch_smem<L>();
+  if (!once) {
+    allow_smem(conv_wgrad_patch_kernel<L>, sm);
+    once = true;
+  }
+  const long ngroups = (P.ns * L::GPS + L::SB - 1) / L::SB;
+  const int grid = (int)std::min<long>(ngroups, std::min(num_cus(), MAXS_C1));
+  hipLaunchKernelGGL((conv_wgrad_patch_kernel<L>), dim3(grid), dim3(512), sm, s, P);
+  return grid;
+}
+int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
+                      long ns) {
+  WgradParams P{obs, static_cast<const bf16 *>(dz1), sw, sb, ns, map, 1.0f / 255.0f};
+  return launch_wgrad<LConv1Wgrad>(s, P);
+}
+int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns) {
+  WgradParams P{a1, static_cast<const bf16 *>(dz2), sw, sb, ns, SampleMap{1, 0, 0, 0, 0}, 1.0f};
+  return launch_wgrad<LConv2Wgrad>(s, P);
+}
+int patch_conv3_wgrad(hipStream_t s, const void *dz3, const void *a2, float *sw, float *sb, long ns) {
+  WgradParams P{a2, static_cast<const bf16 *>(dz3), sw, sb, ns, SampleMap{1, 0, 0, 0, 0}, 1.0f};
+  return launch_wgrad<LConv3Wgrad>(s, P);
+}
+
+} // namespace aleppo

@@ -327,22 +327,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(typename AL::P ap, typenam
 // gemm_tn: weight gradients.  Reduction index p (sample-pixel) is the OUTER dimension of both
 // operands in memory: A(p, m) = dY[p][m] (dense), B(p, n) = im2col(X)[p][n] (gather loader with
 // row = p).  A stage is KP = KT pixels; tiles land in LDS as [p][m] / [p][n] with 16-byte vector
-// writes and fragments are read k-strided (ds_read_b32 for float, ds_read_u16 for bf16).
+// writes and fragments are read k-strided (ds_read_b32 for float, ds_read_b64_tr_b16 for bf16).
 // grid.z = split-K slice; each slice writes an fp32 partial slab [z][M][N] that
 // reduce_slabs_kernel sums in fixed order (deterministic; no atomics).
 // BIAS: n-tile 0 also emits column sums of A (the bias gradient) into bias_slab [z][M].
 // out_scale multiplies the weight slab (conv1: the 1/255 input scaling that forward folds into its epilogue).
 // ------------------------------------------------------------------------------------------------
-template <class T> __device__ __forceinline__ u32x4 lds_gather_k(const T *base, int stride_elems);
-template <> __device__ __forceinline__ u32x4 lds_gather_k<float>(const float *b, int s) {
-  f32x4 f = {b[0], b[s], b[2 * s], b[3 * s]};
-  return __builtin_bit_cast(u32x4, f);
-}
-template <> __device__ __forceinline__ u32x4 lds_gather_k<bf16>(const bf16 *b, int s) {
-  const uint16_t *u = reinterpret_cast<const uint16_t *>(b);
-  auto pk = [&](int j) { return (uint32_t)u[j * s] | ((uint32_t)u[(j + 1) * s] << 16); };
-  return u32x4{pk(0), pk(2), pk(4), pk(6)};
-}
+// k-strided fragment read from an LDS tile stored [k][m] (m contiguous): returns the 16-byte MFMA operand
+// of lane (i = lane&15 -> column m0+i, g = lane>>4 -> this lane's k group) for the atom-k step whose
+// first row is krow0.  float: 4 x ds_read_b32 of rows krow0+4g+j.  bf16: 2 x ds_read_b64_tr_b16 (gfx950
+// hardware transpose): rows krow0+4g..+3 and krow0+16+4g..+3 - a permutation of the step's 32 k's that
+// is identical for both operands, so the product is unchanged; with a row stride = 8 (mod 16) dwords
+// the 8 rows a half-wave touches tile the 64 banks exactly (conflict-free).
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+template <class T> struct KFrag;
+template <> struct KFrag<float> {
+  static constexpr int PAD = 4; // row stride = 4 (mod 8) dwords
+  static __device__ __forceinline__ u32x4 read(const float *tile, int stride, int krow0, int m0, int lane) {
+    const float *b = tile + (krow0 + (lane >> 4) * 4) * stride + m0 + (lane & 15);
+    f32x4 f = {b[0], b[stride], b[2 * stride], b[3 * stride]};
+    return __builtin_bit_cast(u32x4, f);
+  }
+};
+template <> struct KFrag<bf16> {
+  static constexpr int PAD = 16; // elements; (BM/2 + 8) dwords = 8 (mod 16) for BM in {32,64,128}
+  static __device__ __forceinline__ u32x4 read(const bf16 *tile, int stride, int krow0, int m0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const bf16 *p = tile + (krow0 + 4 * g + (i >> 2)) * stride + m0 + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) bf16x4 *lds4;
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + 16 * stride)));
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+};
 
 template <class T, class AL, class BL, int BM, int BN, int WM, int WN, bool BIAS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typename BL::P bp, float *slab,
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
   constexpr int TPR = 256 / KP;           // threads per pixel row (4 bf16 / 8 float)
   constexpr int AVR = BM / VE, BVR = BN / VE; // vectors per pixel row
   constexpr int AV = (AVR + TPR - 1) / TPR, BV = (BVR + TPR - 1) / TPR;
-  constexpr int SAE = BM + VE, SBE = BN + VE; // LDS row length in elements (16 B pad)
+  constexpr int SAE = BM + KFrag<T>::PAD, SBE = BN + KFrag<T>::PAD; // LDS row length in elements
   static_assert(WM * WN == 4 && WTM % 16 == 0 && WTN % 16 == 0, "tile");
   __shared__ __attribute__((aligned(16))) T sA[2][KP * SAE];
   __shared__ __attribute__((aligned(16))) T sB[2][KP * SBE];
@@ -417,14 +434,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
       gload(ks + 1);
 #pragma unroll
     for (int kc = 0; kc < KP / (4 * VE); ++kc) { // one atom-k (16 floats / 32 bf16) per iteration
-      const int prow = kc * 4 * VE + fg * VE;    // first pixel row of this lane's k group
       u32x4 fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        fa[i] = lds_gather_k<T>(&sA[buf][prow * SAE + wm * WTM + i * 16 + fr], SAE);
+        fa[i] = KFrag<T>::read(sA[buf], SAE, kc * 4 * VE, wm * WTM + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        fb[j] = lds_gather_k<T>(&sB[buf][prow * SBE + wn * WTN + j * 16 + fr], SBE);
+        fb[j] = KFrag<T>::read(sB[buf], SBE, kc * 4 * VE, wn * WTN + j * 16, lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -126,7 +126,7 @@ template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const vo
   using BL = DenseLoader<T>;
   constexpr int KP = Atom<T>::KT;
   const dim3 g = grid2(H, 64, FC_IN, 128);
-  const int S = pick_slices(ns, KP, g.x * g.y, MAXS_FC);
+  const int S = 1; // 200 output tiles already fill the chip: no split-K, the "slab" IS the gradient tensor
   const int kc = chunk_for(ns, S, KP);
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
@@ -191,12 +191,18 @@ static int conv1_wgrad_t(hipStream_t s, const void *dz1, const uint32_t *obs, Sa
 
 void conv1_fwd(hipStream_t s, int prec, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
                long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv1_fwd(s, obs, map, W1, b1, a1, ns);
   DISPATCH(prec, conv1_fwd_t<float>(s, obs, map, W1, b1, a1, ns), conv1_fwd_t<bf16>(s, obs, map, W1, b1, a1, ns));
 }
 void conv2_fwd(hipStream_t s, int prec, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv2_fwd(s, a1, W2, b2, a2, ns);
   DISPATCH(prec, conv2_fwd_t<float>(s, a1, W2, b2, a2, ns), conv2_fwd_t<bf16>(s, a1, W2, b2, a2, ns));
 }
 void conv3_fwd(hipStream_t s, int prec, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv3_fwd(s, a2, W3, b3, a3, ns);
   DISPATCH(prec, conv3_fwd_t<float>(s, a2, W3, b3, a3, ns), conv3_fwd_t<bf16>(s, a2, W3, b3, a3, ns));
 }
 void fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H) {
@@ -206,9 +212,13 @@ void fc_dgrad(hipStream_t s, int prec, const void *dh, const void *WfcT, const v
   DISPATCH(prec, fc_dgrad_t<float>(s, dh, WfcT, a3, dz3, ns, H), fc_dgrad_t<bf16>(s, dh, WfcT, a3, dz3, ns, H));
 }
 void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv3_dgrad(s, dz3, W3d, a2, dz2, ns);
   DISPATCH(prec, conv3_dgrad_t<float>(s, dz3, W3d, a2, dz2, ns), conv3_dgrad_t<bf16>(s, dz3, W3d, a2, dz2, ns));
 }
 void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv2_dgrad(s, dz2, W2d, a1, dz1, ns);
   DISPATCH(prec, conv2_dgrad_t<float>(s, dz2, W2d, a1, dz1, ns), conv2_dgrad_t<bf16>(s, dz2, W2d, a1, dz1, ns));
 }
 int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *sw, float *sb, long ns, int H) {
@@ -217,17 +227,23 @@ int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *sw,
   return fc_wgrad_t<float>(s, dh, a3, sw, sb, ns, H);
 }
 int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float *sw, float *sb, long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv3_wgrad(s, dz3, a2, sw, sb, ns);
   if (prec == ALEPPO_BF16)
     return conv3_wgrad_t<bf16>(s, dz3, a2, sw, sb, ns);
   return conv3_wgrad_t<float>(s, dz3, a2, sw, sb, ns);
 }
 int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *sw, float *sb, long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv2_wgrad(s, dz2, a1, sw, sb, ns);
   if (prec == ALEPPO_BF16)
     return conv2_wgrad_t<bf16>(s, dz2, a1, sw, sb, ns);
   return conv2_wgrad_t<float>(s, dz2, a1, sw, sb, ns);
 }
 int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                 long ns) {
+  if (prec == ALEPPO_BF16 && use_patch_kernels())
+    return patch_conv1_wgrad(s, dz1, obs, map, sw, sb, ns);
   if (prec == ALEPPO_BF16)
     return conv1_wgrad_t<bf16>(s, dz1, obs, map, sw, sb, ns);
   return conv1_wgrad_t<float>(s, dz1, obs, map, sw, sb, ns);

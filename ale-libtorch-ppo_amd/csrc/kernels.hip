@@ -542,35 +542,41 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
 // ================================================================================================
 struct ReduceArgs {
   ReduceSeg seg[12];
-  long prefix[13];
+  int cprefix[13]; // prefix of 64-output chunks per segment
   int nseg;
 };
+// one workgroup per 64 consecutive outputs: thread (o = tid&63, q = tid>>6) sums slabs q, q+4, ... and the
+// four partials are combined in fixed order -> deterministic, 4x the memory-level parallelism of a serial scan
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(ReduceArgs a, float *G) {
-  const long total = a.prefix[a.nseg];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int s = 0;
-    while (i >= a.prefix[s + 1])
-      ++s;
-    const long j = i - a.prefix[s];
+  __shared__ float part[4][64];
+  int s = 0;
+  while ((int)blockIdx.x >= a.cprefix[s + 1])
+    ++s;
+  const long j = (long)((int)blockIdx.x - a.cprefix[s]) * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;
+  const long n = a.seg[s].n;
+  float acc = 0.f;
+  if (j < n) {
     const float *p = a.seg[s].slab + j;
-    const long n = a.seg[s].n;
-    float acc = 0.f;
-    for (int k = 0; k < a.seg[s].S; ++k)
+    const int S = a.seg[s].S;
+#pragma unroll 4
+    for (int k = q; k < S; k += 4)
       acc += p[(long)k * n];
-    G[a.seg[s].dst + j] = acc;
   }
+  part[q][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (q == 0 && j < n)
+    G[a.seg[s].dst + j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *G) {
   ReduceArgs a;
   a.nseg = nseg;
-  a.prefix[0] = 0;
+  a.cprefix[0] = 0;
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];
-    a.prefix[i + 1] = a.prefix[i] + segs[i].n;
+    a.cprefix[i + 1] = a.cprefix[i] + (int)((segs[i].n + 63) / 64);
   }
-  const long total = a.prefix[nseg];
-  const int nb = (int)std::min<long>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(nb), dim3(256), 0, s, a, G);
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(a.cprefix[nseg]), dim3(256), 0, s, a, G);
 }
 
 // ================================================================================================

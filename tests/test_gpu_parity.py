@@ -243,6 +243,42 @@ def test_train_vs_oracle(pkg, prec, H, A, N, M):
     eng.close()
 
 
+def test_bf16_patch_kernels_match_generic_kernels(pkg):
+    """the sample-stationary bf16 conv kernels and the generic gather-GEMMs compute the same bf16 math
+    (only the fp32 summation order differs): forward, losses, gradient norm and gradients agree tightly"""
+    H, A, N, M = 512, 6, 200, 2  # 200 samples: ragged vs every group size (2, 4, 6, 8 samples per group)
+    params = hf.fill_params(710, H, A)
+    obs = hf.hf_bytes(711, (N, 4, 84, 84))
+    actions = (hf.hf_u32(712, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(713, (N, A), -1, 1))
+    adv, ret = hf.hf_range(714, (N,), -1, 1), hf.hf_range(715, (N,), -1, 1)
+    masks = (hf.hf_unit(716, N) >= np.float32(0.1)).astype(np.uint8)
+    res = {}
+    for generic in (1, 0):
+        eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
+        eng.set_generic_conv(generic)
+        eng.load_params(params)
+        logits, values = eng.forward(obs[:77])
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 1, M)
+        res[generic] = (logits, values, m, eng.export_grads(), eng.export_params())
+        eng.set_generic_conv(0)
+        eng.close()
+    (l1, v1, m1, g1, p1), (l0, v0, m0, g0, p0) = res[1], res[0]
+    np.testing.assert_allclose(l0, l1, atol=2e-3)
+    np.testing.assert_allclose(v0, v1, atol=2e-3)
+    np.testing.assert_allclose(m0["loss"], m1["loss"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(m0["grad_norm"], m1["grad_norm"], rtol=5e-3)
+    np.testing.assert_allclose(g0, g1, atol=5e-3 * np.abs(g1).max())
+    # and both stay within the documented bf16 bound of the fp32 oracle
+    w = orc.train(params, H, A, obs, actions, old_lp, adv, ret, masks, 1, M)
+    np.testing.assert_allclose(m0["loss"], w["loss"], rtol=1e-2, atol=3e-2)
+    np.testing.assert_allclose(m0["grad_norm"], w["grad_norm"], rtol=5e-2)
+    cw = min(1.0, 0.5 / (float(w["grad_norm"][0, -1]) + 1e-6))
+    c0 = min(1.0, 0.5 / (float(m0["grad_norm"][0, -1]) + 1e-6))
+    np.testing.assert_allclose(g0 / c0, w["last_grads"] / cw, atol=3e-2 * np.abs(w["last_grads"] / cw).max())
+
+
 # ------------------------------------------------------------------ the whole rollout protocol
 def _run_rollouts(pkg, E, T, A, H, rollouts, kind):
     params = hf.fill_params(610, H, A)
