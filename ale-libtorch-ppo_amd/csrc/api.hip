@@ -318,6 +318,7 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(dalloc(reinterpret_cast<char **>(&c->dz2), mb * A2_PIX * A2_C * ts));
   CK(dalloc(reinterpret_cast<char **>(&c->dz3), mb * FC_IN * ts));
   CK(dalloc(&c->h, mb * H * 4));
+  CK(dalloc(&c->hpart, (size_t)FC_SPLITS * E * H * 4));
   CK(dalloc(reinterpret_cast<char **>(&c->dh), mb * H * ts));
   CK(dalloc(&c->logits_b, mb * A * 4));
   CK(dalloc(&c->values_b, mb * 4));
@@ -349,7 +350,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
                  c->d_frames, c->d_noise, c->d_err,  c->adv_n,     c->ret_n,      c->oldlp_n, c->act_n,
                  c->mask_n, c->mask_counts, c->P,    c->G,         c->Gs,         c->M1,      c->M2,
                  c->W2d,   c->W3d,      c->WfcT,      c->a1,        c->a2,         c->a3,      c->dz1,
-                 c->dz2,   c->dz3,      c->h,         c->dh,        c->logits_b,   c->values_b, c->slab,
+                 c->dz2,   c->dz3,      c->h,         c->hpart,     c->dh,        c->logits_b,   c->values_b, c->slab,
                  c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats};
   for (void *p : dev)
     if (p)
@@ -426,7 +427,21 @@ extern "C" int aleppo_export_grads(aleppo_ctx *c, float *flat, size_t count) {
 
 // ------------------------------------------------------------------ rollout
 static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst, float *values_dst, int *actions_dst) {
-  net_forward(c, slot_map(c, slot), c->E);
+  { // conv stack + split-K fc at acting size; the head kernel finishes the fc reduction
+    const SampleMap map = slot_map(c, slot);
+    prof_begin(c, ALEPPO_K_CONV1_FWD);
+    conv1_fwd(c->stream, c->prec, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, c->E);
+    prof_end(c, ALEPPO_K_CONV1_FWD);
+    prof_begin(c, ALEPPO_K_CONV2_FWD);
+    conv2_fwd(c->stream, c->prec, c->a1, Pcw(c, P_W2), Pf(c, P_B2), c->a2, c->E);
+    prof_end(c, ALEPPO_K_CONV2_FWD);
+    prof_begin(c, ALEPPO_K_CONV3_FWD);
+    conv3_fwd(c->stream, c->prec, c->a2, Pcw(c, P_W3), Pf(c, P_B3), c->a3, c->E);
+    prof_end(c, ALEPPO_K_CONV3_FWD);
+    prof_begin(c, ALEPPO_K_FC_FWD);
+    fc_fwd_splitk(c->stream, c->prec, c->a3, Pcw(c, P_WFC), c->hpart, c->E, c->H);
+    prof_end(c, ALEPPO_K_FC_FWD);
+  }
   const float *dn = nullptr;
   if (noise) {
     std::memcpy(c->h_noise, noise, (size_t)c->E * c->A * 4);
@@ -436,8 +451,8 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst
   int64_t *pinned_dev = nullptr;
   HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), c->h_actions, 0));
   prof_begin(c, ALEPPO_K_INFER_HEAD);
-  launch_infer_head(c->stream, c->h, Pf(c, P_WH), Pf(c, P_BH), dn, c->cfg.seed, c->rng_counter++, logits_dst,
-                    values_dst, actions_dst, pinned_dev, c->E, c->H, c->A);
+  launch_infer_head(c->stream, c->hpart, FC_SPLITS, Pf(c, P_BFC), Pf(c, P_WH), Pf(c, P_BH), dn, c->cfg.seed,
+                    c->rng_counter++, logits_dst, values_dst, actions_dst, pinned_dev, c->E, c->H, c->A);
   prof_end(c, ALEPPO_K_INFER_HEAD);
   HIPCHK(c, hipGetLastError());
   return ALEPPO_OK;
@@ -533,10 +548,33 @@ extern "C" int aleppo_record_step(aleppo_ctx *c, const float *rewards, const uin
 extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int location, const float *rewards,
                            const uint8_t *terminated, const uint8_t *truncated, const uint8_t *episode_start) {
   CHECK_CTX(c);
-  int rc = do_push(c, frames, kind, location, episode_start);
+  if (!frames || !rewards || !terminated || !truncated || !episode_start)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (kind != ALEPPO_FRAMES_84 && kind != ALEPPO_FRAMES_RAW_PAIR)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown frame kind");
+  if (c->t >= c->T)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
+  HIPCHK(c, hipEventSynchronize(c->ev_tmp)); // staging reuse guard (normally long finished: act() syncs)
+  // ONE upload: the packed step record lands in its final slot; ingest reads the start flags from it
+  const int E = c->E;
+  std::memcpy(c->h_step, rewards, (size_t)E * 4);
+  std::memcpy(c->h_step + 4 * (size_t)E, terminated, E);
+  std::memcpy(c->h_step + 5 * (size_t)E, truncated, E);
+  std::memcpy(c->h_step + 6 * (size_t)E, episode_start, E);
+  uint8_t *rec = c->step_rec + (size_t)c->t * c->step_rec_bytes;
+  HIPCHK(c, hipMemcpyAsync(rec, c->h_step, (size_t)7 * E, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *df = nullptr;
+  int rc = upload_frames(c, frames, kind, location, &df);
   if (rc)
     return rc;
-  return do_record(c, rewards, terminated, truncated, episode_start);
+  prof_begin(c, ALEPPO_K_INGEST);
+  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, rec + 6 * (size_t)E, c->obs, E, c->T + 1, c->t,
+                c->t + 1);
+  prof_end(c, ALEPPO_K_INGEST);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
+  c->t++;
+  return ALEPPO_OK;
 }
 extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
   CHECK_CTX(c);

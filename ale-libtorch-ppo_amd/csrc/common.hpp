@@ -16,6 +16,7 @@ constexpr int A2_PIX = 81, A2_C = 64;       // conv2 out 9x9x64
 constexpr int A3_PIX = 49, A3_C = 64;       // conv3 out 7x7x64
 constexpr int FC_IN = 3136;
 constexpr int MAX_ACTIONS = 18;
+constexpr int FC_SPLITS = 7; // split-K slices of the acting-size fc forward (3136 = 7 * 448)
 // split-K slice caps of the wgrad slabs (gemm_launch.hip) and of the head kernel's partial slabs
 constexpr int MAXS_C1 = 256, MAXS_C2 = 256, MAXS_C3 = 256, MAXS_FC = 4, MAXS_HEAD = 256;
 
@@ -99,6 +100,7 @@ struct Ctx {
   // ---- activations (T unless noted) ----
   void *a1 = nullptr, *a2 = nullptr, *a3 = nullptr; // [maxB][400][32], [maxB][81][64], [maxB][49][64]
   float *h = nullptr;                               // [maxB][H] fp32
+  float *hpart = nullptr;                           // [FC_SPLITS][E][H] acting-size fc partial sums
   void *dh = nullptr;                               // [maxB][H] T
   void *dz3 = nullptr, *dz2 = nullptr, *dz1 = nullptr;
   float *logits_b = nullptr, *values_b = nullptr;   // [maxB][A], [maxB] (forward-only API / debug)
@@ -133,12 +135,13 @@ int set_err(Ctx *c, int code, const std::string &msg);
 void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
                    uint32_t *obs, int E, int slots, int t_src, int t_dst);
 void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, int dst);
-void launch_infer_head(hipStream_t s, const float *h, const float *Wh, const float *bh, const float *noise,
-                       uint64_t seed, uint64_t counter, float *logits_t, float *values_t, int *actions_t,
-                       int64_t *pinned, int E, int H, int A);
+void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
+                       const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
+                       float *values_t, int *actions_t, int64_t *pinned, int E, int H, int A);
 void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
                 const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
                 int *err, int E, int T, int A, float gamma, float lambda);
+
 void launch_adv_norm(hipStream_t s, float *adv_n, const uint8_t *mask_n, float *stats, long n, int phase);
 void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long B, int M);
 void launch_head_train(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
@@ -189,6 +192,7 @@ void conv1_fwd(hipStream_t s, int prec, const uint32_t *obs, SampleMap map, cons
 void conv2_fwd(hipStream_t s, int prec, const void *a1, const void *W2, const float *b2, void *a2, long ns);
 void conv3_fwd(hipStream_t s, int prec, const void *a2, const void *W3, const float *b3, void *a3, long ns);
 void fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H);
+void fc_fwd_splitk(hipStream_t s, int prec, const void *a3, const void *Wfc, float *hpart, long ns, int H);
 void fc_dgrad(hipStream_t s, int prec, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H);
 void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns);
 void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns);

@@ -45,6 +45,13 @@ struct LConv3Fwd {
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
                        OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
 };
+// acting-size variants (ns <= 256): one sample per group so that every CU gets a workgroup
+struct LConv2FwdSmall : LConv2Fwd {
+  static constexpr int SB = 1;
+};
+struct LConv3FwdSmall : LConv3Fwd {
+  static constexpr int SB = 1;
+};
 // dgrad: input = dY [OH][OW][OCK], output pixel grid PH x PW, taps TH x TW, source pixel (y-dy, x-dx)
 struct LConv3Dgrad {
   static constexpr int MODE = PM_DGRAD;

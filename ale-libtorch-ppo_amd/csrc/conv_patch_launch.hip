@@ -54,12 +54,18 @@ void patch_conv1_fwd(hipStream_t s, const uint32_t *obs, SampleMap map, const vo
 void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
   PatchParams P{a1, static_cast<const bf16 *>(W2), b2, nullptr, static_cast<bf16 *>(a2), ns, SampleMap{1, 0, 0, 0, 0},
                 1.0f};
-  launch_patch<LConv2Fwd>(s, P);
+  if (ns <= 256)
+    launch_patch<LConv2FwdSmall>(s, P);
+  else
+    launch_patch<LConv2Fwd>(s, P);
 }
 void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
   PatchParams P{a2, static_cast<const bf16 *>(W3), b3, nullptr, static_cast<bf16 *>(a3), ns, SampleMap{1, 0, 0, 0, 0},
                 1.0f};
-  launch_patch<LConv3Fwd>(s, P);
+  if (ns <= 256)
+    launch_patch<LConv3FwdSmall>(s, P);
+  else
+    launch_patch<LConv3Fwd>(s, P);
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),

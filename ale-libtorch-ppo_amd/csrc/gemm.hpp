@@ -188,6 +188,25 @@ template <class OutT, bool RELU> struct EpiBiasAct {
   }
 };
 
+// split-K partial sums: out[z][m*ld + n] = v  (no bias; the consumer adds the slices in fixed order)
+struct EpiPartial {
+  struct P {
+    float *out;
+    long ld;
+    long zstride;
+  };
+  struct Row {
+    long off;
+    bool ok;
+  };
+  static __device__ __forceinline__ void set_z(P &p, int z) { p.out += (long)z * p.zstride; }
+  static __device__ __forceinline__ Row row(const P &p, int m, int M) { return Row{(long)m * p.ld, m < M}; }
+  static __device__ __forceinline__ void store(const P &p, const Row &r, int n, int N, float v) {
+    if (r.ok && n < N)
+      p.out[r.off + n] = v;
+  }
+};
+
 // dgrad epilogue: out = v * [act > 0]  (gradient through the ReLU that produced `act`).
 // MAP 0: linear rows (off = m*ld).  MAP 1: conv2 parity class z=(py,px): row (n,y',x') ->
 // pixel (2y'+py, 2x'+px) of the [n][20][20][32] tensor.

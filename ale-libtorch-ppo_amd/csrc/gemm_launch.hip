@@ -65,6 +65,26 @@ static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float
                        bp, ep, (int)ns, H, FC_IN);
 }
 
+// acting-size fc (ns <= 256 rows): split the 3136-deep reduction over FC_SPLITS grid.z slices so 100s of
+// workgroups share it; slices land in hpart[z][ns][H] and the head kernel adds them (+ bias) in fixed order
+template <class T> static void fc_fwd_splitk_t(hipStream_t s, const void *a3, const void *Wfc, float *hpart, long ns, int H) {
+  using AL = DenseLoader<T>;
+  using BL = DenseLoader<T>;
+  using EP = EpiPartial;
+  constexpr int KC = FC_IN / FC_SPLITS; // 448 = 7*64 = 14*32
+  typename AL::P ap{static_cast<const T *>(a3), FC_IN, KC};
+  typename BL::P bp{static_cast<const T *>(Wfc), FC_IN, KC};
+  typename EP::P ep{hpart, H, ns * (long)H};
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 32, 32, 2, 2>), grid2(ns, 32, H, 32, FC_SPLITS), dim3(256), 0, s,
+                     ap, bp, ep, (int)ns, H, KC);
+}
+void fc_fwd_splitk(hipStream_t s, int prec, const void *a3, const void *Wfc, float *hpart, long ns, int H) {
+  if (prec == ALEPPO_BF16)
+    fc_fwd_splitk_t<bf16>(s, a3, Wfc, hpart, ns, H);
+  else
+    fc_fwd_splitk_t<float>(s, a3, Wfc, hpart, ns, H);
+}
+
 // ------------------------------------------------------------------ dgrad
 template <class T>
 static void fc_dgrad_t(hipStream_t s, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H) {

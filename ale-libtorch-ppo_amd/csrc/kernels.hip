@@ -35,26 +35,27 @@ __device__ __forceinline__ float block_sum_256(float v, float *s4) {
 // grid (7 bands of 12 output rows, E), 256 threads; a band needs exactly 30 raw rows per frame.
 // ================================================================================================
 template <bool RAW>
-__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ lut,
+__global__ __launch_bounds__(512) void ingest_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ lut,
                                                       const uint8_t *__restrict__ start, uint32_t *obs, int slots,
                                                       int t_src, int t_dst) {
   const int e = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) uint8_t sraw[2 * 30 * RAW_W];
   __shared__ uint8_t slut[256];
   if (RAW) {
-    for (int v = tid; v < 600; v += 256) { // 2 frames x 30 rows x 10 16-byte vectors, coalesced
+    for (int v = tid; v < 600; v += 512) { // 2 frames x 30 rows x 10 16-byte vectors, coalesced
       const int f = v / 300, r = v - f * 300;
       const u32x4 *src =
           reinterpret_cast<const u32x4 *>(frames + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)band * 30 * RAW_W);
       reinterpret_cast<u32x4 *>(sraw)[v] = src[r];
     }
-    slut[tid] = lut[tid];
+    if (tid < 256)
+      slut[tid] = lut[tid];
     __syncthreads();
   }
   const bool st = start[e] != 0;
   const uint32_t *src = obs + ((size_t)e * slots + t_src) * FRAME_PIX;
   uint32_t *dst = obs + ((size_t)e * slots + t_dst) * FRAME_PIX;
-  for (int pix = tid; pix < 12 * 84; pix += 256) {
+  for (int pix = tid; pix < 12 * 84; pix += 512) {
     const int il = pix / 84, j = pix - il * 84, i = band * 12 + il;
     uint32_t v;
     if (RAW) {
@@ -83,9 +84,9 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__
 void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
                    uint32_t *obs, int E, int slots, int t_src, int t_dst) {
   if (raw)
-    hipLaunchKernelGGL(ingest_kernel<true>, dim3(7, E), dim3(256), 0, s, frames, lut, start, obs, slots, t_src, t_dst);
+    hipLaunchKernelGGL(ingest_kernel<true>, dim3(7, E), dim3(512), 0, s, frames, lut, start, obs, slots, t_src, t_dst);
   else
-    hipLaunchKernelGGL(ingest_kernel<false>, dim3(7, E), dim3(256), 0, s, frames, lut, start, obs, slots, t_src,
+    hipLaunchKernelGGL(ingest_kernel<false>, dim3(7, E), dim3(512), 0, s, frames, lut, start, obs, slots, t_src,
                        t_dst);
 }
 
@@ -121,7 +122,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   }
 }
 
-__global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ h, const float *__restrict__ Wh,
+// h = sum of the fc split-K slices + fc bias, formed on the fly (all NSPLIT*8 loads of a lane are independent)
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ hpart, int nsplit,
+                                                          const float *__restrict__ bfc, const float *__restrict__ Wh,
                                                           const float *__restrict__ bh, const float *__restrict__ noise,
                                                           uint64_t seed, uint64_t counter, float *logits_t,
                                                           float *values_t, int *actions_t, int64_t *pinned, int E, int H,
@@ -131,11 +135,32 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
   const int e = blockIdx.x * 4 + wave;
   if (e >= E)
     return;
-  const float *hr = h + (size_t)e * H;
+  float hv[8]; // H <= 512
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = lane + 64 * i;
+    float v = 0.f;
+    if (j < H) {
+      float part[NSPLIT];
+#pragma unroll
+      for (int z = 0; z < NSPLIT; ++z)
+        part[z] = hpart[((size_t)z * E + e) * H + j];
+      v = bfc[j];
+#pragma unroll
+      for (int z = 0; z < NSPLIT; ++z)
+        v += part[z];
+    }
+    hv[i] = v;
+  }
+  (void)nsplit;
   for (int a = 0; a <= A; ++a) {
     float s = 0.f;
-    for (int j = lane; j < H; j += 64)
-      s += hr[j] * Wh[(size_t)a * H + j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = lane + 64 * i;
+      if (j < H)
+        s += hv[i] * Wh[(size_t)a * H + j];
+    }
     s = wave_sum(s);
     if (lane == 0)
       sz[wave][a] = s + bh[a];
@@ -150,14 +175,20 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
       sum += expf(z[k] - mx);
     int best = 0;
     float bv = -1.f;
+    uint32_t c[4] = {0, 0, 0, 0};
     for (int k = 0; k < A; ++k) {
       const float p = expf(z[k] - mx) / sum;
       float q;
       if (noise) {
         q = noise[(size_t)e * A + k];
       } else {
-        uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)e, (uint32_t)(k >> 2)};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        if ((k & 3) == 0) { // one Philox4x32-10 block serves four actions
+          c[0] = (uint32_t)counter;
+          c[1] = (uint32_t)(counter >> 32);
+          c[2] = (uint32_t)e;
+          c[3] = (uint32_t)(k >> 2);
+          philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        }
         const float u = ((float)(c[k & 3] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0,1)
         q = -logf(u);
       }
@@ -173,11 +204,12 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
     pinned[e] = best;
   }
 }
-void launch_infer_head(hipStream_t s, const float *h, const float *Wh, const float *bh, const float *noise,
-                       uint64_t seed, uint64_t counter, float *logits_t, float *values_t, int *actions_t,
-                       int64_t *pinned, int E, int H, int A) {
-  hipLaunchKernelGGL(infer_head_kernel, dim3((E + 3) / 4), dim3(256), 0, s, h, Wh, bh, noise, seed, counter, logits_t,
-                     values_t, actions_t, pinned, E, H, A);
+void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
+                       const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
+                       float *values_t, int *actions_t, int64_t *pinned, int E, int H, int A) {
+  // nsplit is always FC_SPLITS on the acting path
+  hipLaunchKernelGGL(infer_head_kernel<FC_SPLITS>, dim3((E + 3) / 4), dim3(256), 0, s, hpart, nsplit, bfc, Wh, bh,
+                     noise, seed, counter, logits_t, values_t, actions_t, pinned, E, H, A);
 }
 
 // ================================================================================================
@@ -229,24 +261,36 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
     adv_n[n] = a;
     ret_n[n] = a + v;           // buffer.cc:70-71
     mask_n[n] = st ? 0 : 1;     // buffer.cc:74
-    act_n[n] = actions_tm[(size_t)t * E + e];
-    const float *z = logits_tm + ((size_t)t * E + e) * A;
-    float mx = z[0];
-    for (int k = 1; k < A; ++k)
-      mx = fmaxf(mx, z[k]);
-    float s = 0.f;
-    for (int k = 0; k < A; ++k)
-      s += expf(z[k] - mx);
-    const float lse = mx + logf(s);
-    for (int k = 0; k < A; ++k)
-      oldlp_n[n * A + k] = z[k] - lse; // train.cc:279 normalize_logits
     last = a;
     nv = v;
   }
 }
+// the embarrassingly parallel part of prepare_batch (train.cc:272-283): old log-probs + actions, one thread
+// per (t, e) slot, written env-major
+__global__ void oldlp_kernel(const float *__restrict__ logits_tm, const int *__restrict__ actions_tm, float *oldlp_n,
+                             int *act_n, int E, int T, int A) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x; // time-major index t*E + e
+  if (i >= (long)E * T)
+    return;
+  const int t = (int)(i / E), e = (int)(i - (long)t * E);
+  const size_t n = (size_t)e * T + t;
+  act_n[n] = actions_tm[i];
+  const float *z = logits_tm + i * A;
+  float mx = z[0];
+  for (int k = 1; k < A; ++k)
+    mx = fmaxf(mx, z[k]);
+  float s = 0.f;
+  for (int k = 0; k < A; ++k)
+    s += expf(z[k] - mx);
+  const float lse = mx + logf(s);
+  for (int k = 0; k < A; ++k)
+    oldlp_n[n * A + k] = z[k] - lse; // train.cc:279 normalize_logits
+}
 void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
                 const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
                 int *err, int E, int T, int A, float gamma, float lambda) {
+  hipLaunchKernelGGL(oldlp_kernel, dim3((unsigned)(((long)E * T + 255) / 256)), dim3(256), 0, s, logits_tm, actions_tm,
+                     oldlp_n, act_n, E, T, A);
   hipLaunchKernelGGL(gae_kernel, dim3((E + 63) / 64), dim3(64), 0, s, step_rec, rec_bytes, values_tm, logits_tm,
                      actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n, err, E, T, A, gamma, lambda);
 }

@@ -77,25 +77,51 @@ def run(args):
     base_ptr = frames.data_ptr()
     rng = np.random.default_rng(42 + rank)
 
-    start = np.ones(E, np.uint8)
-    rewards = np.zeros(E, np.float32)
-    real_steps = 0
-
-    def one_rollout_and_update(count):
-        nonlocal start, rewards, real_steps
+    # the synthetic emulator outputs of every slot of every rollout are generated BEFORE the timed region
+    # (the emulator is out of scope: it stays on host threads); the slot protocol of SURVEY app. A is kept:
+    # terminated p=1/200, truncated p=1/2000, each followed by one masked episode-start slot, stale rewards
+    def synth_rollout(start0, rewards0):
+        rew = np.zeros((T, E), np.float32); te = np.zeros((T, E), np.uint8)
+        tr = np.zeros((T, E), np.uint8); st = np.zeros((T, E), np.uint8)
+        start, rewards = start0, rewards0
         for t in range(T):
-            eng.act()  # forward + sample; actions land in pinned host memory (an emulator would read them here)
             u = rng.random(E)
             term = ((u < 1 / 200) & (start == 0)).astype(np.uint8)
             trunc = ((u >= 1 / 200) & (u < 1 / 200 + 1 / 2000) & (start == 0)).astype(np.uint8)
             r = np.where(rng.random(E) < 0.05, rng.choice([1.0, 4.0, 7.0], E), 0.0).astype(np.float32)
             rewards = np.where(start == 1, rewards, r).astype(np.float32)
-            eng.step(None, rewards, term, trunc, start, kind=pkg.FRAMES_RAW_PAIR, device_ptr=base_ptr + t * slot_bytes)
-            if count:
-                real_steps += int((start == 0).sum())
+            rew[t], te[t], tr[t], st[t] = rewards, term, trunc, start
             start = (term | trunc).astype(np.uint8)
+        return (rew, te, tr, st), start, rewards
+
+    start, rewards = np.ones(E, np.uint8), np.zeros(E, np.float32)
+    plans = []
+    for _ in range(args.warmup + args.steps + 2):
+        plan, start, rewards = synth_rollout(start, rewards)
+        plans.append(plan)
+    real_steps = 0
+    plan_i = 0
+    split = [0.0, 0.0, 0.0]  # host wall seconds inside the timed region: act+step loop, finish_rollout, train
+
+    def one_rollout_and_update(count):
+        nonlocal real_steps, plan_i
+        rew, te, tr, st = plans[plan_i]
+        plan_i += 1
+        t0 = time.perf_counter()
+        for t in range(T):
+            eng.act()  # forward + sample; actions land in pinned host memory (an emulator would read them here)
+            eng.step(None, rew[t], te[t], tr[t], st[t], kind=pkg.FRAMES_RAW_PAIR, device_ptr=base_ptr + t * slot_bytes)
+        t1 = time.perf_counter()
         eng.finish_rollout()
-        return eng.train(2.5e-4, epochs, M)
+        t2 = time.perf_counter()
+        m = eng.train(2.5e-4, epochs, M)
+        t3 = time.perf_counter()
+        if count:
+            real_steps += int((st == 0).sum())
+            split[0] += t1 - t0
+            split[1] += t2 - t1
+            split[2] += t3 - t2
+        return m
 
     def barrier():
         if world > 1:
@@ -119,45 +145,53 @@ def run(args):
         dist.all_reduce(steps_all, op=dist.ReduceOp.SUM)
     dt = tmax.item()
     value = steps_all.item() / dt
-    log(f"timed {args.steps} steps in {dt:.3f} s -> {value:.0f} env-steps/s")
+    log(f"timed {args.steps} steps in {dt:.3f} s -> {value:.0f} env-steps/s; per step: slots "
+        f"{split[0] / args.steps * 1e3:.2f} ms, finish_rollout {split[1] / args.steps * 1e3:.2f} ms, "
+        f"train {split[2] / args.steps * 1e3:.2f} ms")
 
-    # ---- separate profiling pass (HIP events around every launch, on the stream the kernels run on)
+    # ---- separate profiling passes (HIP events around every launch, on the stream the kernels run on):
+    # one rollout (acting shapes) and one update (training shapes) are profiled separately
     roofline = None
-    kern = {}
+    phase = {}
     if rank == 0:
+        def rollout_only():
+            rew, te, tr, st = plans[-1]
+            for t in range(T):
+                eng.act()
+                eng.step(None, rew[t], te[t], tr[t], st[t], kind=pkg.FRAMES_RAW_PAIR,
+                         device_ptr=base_ptr + t * slot_bytes)
+            eng.finish_rollout()
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); rollout_only(); eng.synchronize(); phase["rollout_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter(); eng.train(2.5e-4, epochs, M); phase["update_ms"] = (time.perf_counter() - t0) * 1e3
         eng.profile(True)
         eng.profile_reset()
-        one_rollout_and_update(False)
-        for k in pkg.KERNEL_CLASSES:
-            kern[k] = eng.profile_read(k)
+        rollout_only()
+        act = {k: eng.profile_read(k) for k in pkg.KERNEL_CLASSES}
+        eng.profile_reset()
+        eng.train(2.5e-4, epochs, M)
+        trn = {k: eng.profile_read(k) for k in pkg.KERNEL_CLASSES}
         eng.profile(False)
         B = E * T // M
-        n_train = epochs * M
-        # training launches of the fwd kernels are the last n_train ... simpler: total time split by launch count
-        tot = {}
-        for k, (ms, n) in kern.items():
-            tot[k] = ms * n
-        gemm = {k: v for k, v in tot.items() if k in KFLOP}
+        gemm = {k: v[0] * v[1] for k, v in trn.items() if k in KFLOP}
         dom = max(gemm, key=gemm.get)
-        # fwd kernels also ran (T+1) acting launches of E samples in this pass: use per-sample flops x samples seen
-        samples = B * n_train + (E * (T + 1) if dom.endswith("_fwd") else 0)
-        achieved = KFLOP[dom] * samples / (tot[dom] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        achieved = KFLOP[dom] * B / (trn[dom][0] * 1e-3) / 1e12  # per launch: B samples
         roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=None,
-                        avg_launch_ms=round(kern[dom][0], 4), launches=kern[dom][1])
-        # HBM-bound leg: ingest (74,256 B per env-step algorithmic) and GAE (23 B per (env,t))
-        ing_ms, ing_n = kern["ingest"]
-        gae_ms, gae_n = kern["gae"]
-        hbm = dict(ingest_GBps=round(74256 * E / (ing_ms * 1e-3) / 1e9, 1) if ing_ms else None,
-                   ingest_frac=round(74256 * E / (ing_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if ing_ms else None,
-                   gae_GBps=round(23 * E * T / (gae_ms * 1e-3) / 1e9, 2) if gae_ms else None,
-                   adam_GBps=round(28 * eng.param_count / (kern["adam"][0] * 1e-3) / 1e9, 1) if kern["adam"][0] else None)
-        roofline["hbm_kernels"] = hbm
-        roofline["per_kernel_ms"] = {k: round(v[0], 4) for k, v in kern.items()}
-        all_gemm_ms = sum(gemm.values())
-        flops = sum(KFLOP[k] * (B * n_train + (E * (T + 1) if k.endswith("_fwd") else 0)) for k in gemm)
-        roofline["all_gemm_TFLOPs"] = round(flops / (all_gemm_ms * 1e-3) / 1e12, 2)
+                        frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(trn[dom][0], 4),
+                        launches=trn[dom][1], flop_per_launch=KFLOP[dom] * B)
+        upd_ms = sum(v[0] * v[1] for v in trn.values())
+        roofline["update_all_kernels_TFLOPs"] = round(sum(KFLOP.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e12, 2)
+        roofline["update_kernel_ms_per_minibatch"] = {k: round(v[0], 4) for k, v in trn.items() if v[1]}
+        roofline["acting_kernel_ms_per_step"] = {k: round(v[0], 4) for k, v in act.items() if v[1]}
+        ing_ms = act["ingest"][0]
+        roofline["hbm_kernels"] = dict(
+            ingest_GBps=round(74256 * E / (ing_ms * 1e-3) / 1e9, 1), ingest_frac=round(74256 * E / (ing_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            gae_GBps=round(23 * E * T / (act["gae"][0] * 1e-3) / 1e9, 2),
+            adam_GBps=round(28 * eng.param_count / (trn["adam"][0] * 1e-3) / 1e9, 1),
+            head_GBps=round((97 + 2 * 512 * 4) * B / (trn["head"][0] * 1e-3) / 1e9, 1))
+        roofline["phase_wall_ms"] = {k: round(v, 3) for k, v in phase.items()}
 
     # ---- CPU baseline beside it (rank 0, N=1 only): the reference's own compiled CPU-libtorch path
     cpu = None
