@@ -242,6 +242,13 @@ class Engine:
         n = C.c_size_t()
         _check(lib().aleppo_param_count(self._ctx, C.byref(n)), self._ctx)
         self.param_count = n.value
+        self._f_act = lib().aleppo_act
+        self._f_step = lib().aleppo_step
+        self._f_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]
+        self._act_ptr = C.POINTER(C.c_int64)()
+        self._act_out = C.byref(self._act_ptr)
+        self.actions = None  # view of the pinned action buffer, valid after the first act
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -273,7 +280,8 @@ class Engine:
         p = C.POINTER(C.c_int64)()
         n = None if noise is None else _f32(noise)
         self._c(lib().aleppo_act(self._ctx, _ptr(n), C.byref(p)))
-        return np.ctypeslib.as_array(p, shape=(self.E,))  # view of the pinned buffer
+        self.actions = np.ctypeslib.as_array(p, shape=(self.E,))  # view of the pinned buffer
+        return self.actions
 
     def push_frames(self, frames, episode_start, kind=FRAMES_84, device_ptr=None):
         st = _u8(episode_start)
@@ -291,6 +299,19 @@ class Engine:
         loc = DEVICE if device_ptr is not None else HOST
         self._c(lib().aleppo_step(self._ctx, fr, kind, loc, _ptr(_f32(rewards)), _ptr(_u8(terminated)),
                                   _ptr(_u8(truncated)), _ptr(_u8(episode_start))))
+
+    # -- low-overhead variants for tight host loops: raw addresses, no numpy conversions --
+    def act_fast(self):
+        """aleppo_act with the built-in RNG; returns nothing (read self.actions, a view of the pinned buffer)"""
+        rc = self._f_act(self._ctx, None, self._act_out)
+        if rc:
+            self._c(rc)
+
+    def step_ptr(self, frames_addr, location, kind, rewards_addr, term_addr, trunc_addr, start_addr):
+        """aleppo_step on raw addresses (host arrays must stay alive and be C-contiguous of the right dtype)"""
+        rc = self._f_step(self._ctx, frames_addr, kind, location, rewards_addr, term_addr, trunc_addr, start_addr)
+        if rc:
+            self._c(rc)
 
     def set_gray_lut(self, lut):
         self._c(lib().aleppo_set_gray_lut(self._ctx, _ptr(_u8(lut))))

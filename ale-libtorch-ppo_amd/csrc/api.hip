@@ -4,6 +4,8 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <rccl/rccl.h>
 
@@ -218,6 +220,8 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   // same checks as Rollout::Rollout (rollout.cc:48-59) where they apply
   if (cfg->num_envs <= 0)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "Total environments must be greater than 0.");
+  if (cfg->num_envs > MAX_ENVS_PER_RANK)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "num_envs per rank must be <= 8192");
   if (cfg->horizon <= 0)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "Horizon must be greater than 0.");
   if (cfg->frame_stack != 4)
@@ -280,18 +284,21 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(dalloc(&c->d_frames, (size_t)E * 2 * RAW_H * RAW_W));
   CK(dalloc(&c->d_noise, (size_t)E * A * 4));
   CK(dalloc(&c->d_err, 16));
+  CK(dalloc(&c->d_done, 16));
   {
     uint8_t ident[256];
     for (int i = 0; i < 256; ++i)
       ident[i] = (uint8_t)i;
     CK(hipMemcpy(c->lut, ident, 256, hipMemcpyHostToDevice));
   }
-  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_actions), (size_t)E * 8, hipHostMallocMapped));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_actions), (size_t)(E + 8) * 8, hipHostMallocMapped));
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_step), c->step_rec_bytes + E, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_rec), c->step_rec_bytes * T, hipHostMallocDefault));
+  std::memset(c->h_rec, 0, c->step_rec_bytes * T);
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_frames), (size_t)E * 2 * RAW_H * RAW_W, hipHostMallocDefault));
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_noise), (size_t)E * A * 4, hipHostMallocDefault));
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), 16, hipHostMallocDefault));
-  std::memset(c->h_actions, 0, (size_t)E * 8);
+  std::memset(c->h_actions, 0, (size_t)(E + 8) * 8);
   CK(dalloc(&c->adv_n, (size_t)c->N * 4));
   CK(dalloc(&c->ret_n, (size_t)c->N * 4));
   CK(dalloc(&c->oldlp_n, (size_t)c->N * A * 4));
@@ -347,7 +354,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
   if (c->nccl_comm)
     ncclCommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
   void *dev[] = {c->obs,   c->step_rec, c->values_tm, c->logits_tm, c->actions_tm, c->lut,     c->d_start,
-                 c->d_frames, c->d_noise, c->d_err,  c->adv_n,     c->ret_n,      c->oldlp_n, c->act_n,
+                 c->d_frames, c->d_noise, c->d_err,  c->d_done, c->adv_n,     c->ret_n,      c->oldlp_n, c->act_n,
                  c->mask_n, c->mask_counts, c->P,    c->G,         c->Gs,         c->M1,      c->M2,
                  c->W2d,   c->W3d,      c->WfcT,      c->a1,        c->a2,         c->a3,      c->dz1,
                  c->dz2,   c->dz3,      c->h,         c->hpart,     c->dh,        c->logits_b,   c->values_b, c->slab,
@@ -357,7 +364,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
       hipFree(p);
   if (c->Pc && c->Pc != c->P)
     hipFree(c->Pc);
-  void *host[] = {c->h_actions, c->h_step, c->h_frames, c->h_noise, c->h_err, c->h_metric_red};
+  void *host[] = {c->h_actions, c->h_step, c->h_rec, c->h_frames, c->h_noise, c->h_err, c->h_metric_red};
   for (void *p : host)
     if (p)
       hipHostFree(p);
@@ -426,9 +433,16 @@ extern "C" int aleppo_export_grads(aleppo_ctx *c, float *flat, size_t count) {
 }
 
 // ------------------------------------------------------------------ rollout
-static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst, float *values_dst, int *actions_dst) {
+static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst, float *values_dst, int *actions_dst,
+                  bool publish) {
   { // conv stack + split-K fc at acting size; the head kernel finishes the fc reduction
     const SampleMap map = slot_map(c, slot);
+    if (c->prec == ALEPPO_BF16 && use_patch_kernels()) { // one launch: a1/a2 never leave LDS
+      prof_begin(c, ALEPPO_K_CONV1_FWD);
+      patch_act_convs(c->stream, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), Pcw(c, P_W2), Pf(c, P_B2), Pcw(c, P_W3),
+                      Pf(c, P_B3), c->a3, c->E);
+      prof_end(c, ALEPPO_K_CONV1_FWD);
+    } else {
     prof_begin(c, ALEPPO_K_CONV1_FWD);
     conv1_fwd(c->stream, c->prec, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, c->E);
     prof_end(c, ALEPPO_K_CONV1_FWD);
@@ -438,6 +452,7 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst
     prof_begin(c, ALEPPO_K_CONV3_FWD);
     conv3_fwd(c->stream, c->prec, c->a2, Pcw(c, P_W3), Pf(c, P_B3), c->a3, c->E);
     prof_end(c, ALEPPO_K_CONV3_FWD);
+    }
     prof_begin(c, ALEPPO_K_FC_FWD);
     fc_fwd_splitk(c->stream, c->prec, c->a3, Pcw(c, P_WFC), c->hpart, c->E, c->H);
     prof_end(c, ALEPPO_K_FC_FWD);
@@ -451,8 +466,13 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst
   int64_t *pinned_dev = nullptr;
   HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), c->h_actions, 0));
   prof_begin(c, ALEPPO_K_INFER_HEAD);
+  if (publish)
+    c->ticket++;
+  if (c->dbg_no_publish)
+    pinned_dev = nullptr;
   launch_infer_head(c->stream, c->hpart, FC_SPLITS, Pf(c, P_BFC), Pf(c, P_WH), Pf(c, P_BH), dn, c->cfg.seed,
-                    c->rng_counter++, logits_dst, values_dst, actions_dst, pinned_dev, c->E, c->H, c->A);
+                    c->rng_counter++, logits_dst, values_dst, actions_dst, pinned_dev, publish ? c->d_done : nullptr,
+                    c->ticket, c->E, c->H, c->A);
   prof_end(c, ALEPPO_K_INFER_HEAD);
   HIPCHK(c, hipGetLastError());
   return ALEPPO_OK;
@@ -467,10 +487,25 @@ extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **act
     c->need_carry = false;
   }
   const size_t o = (size_t)c->t * c->E;
-  int rc = do_act(c, noise, c->t, c->logits_tm + o * c->A, c->values_tm + o, c->actions_tm + o);
+  int rc = do_act(c, noise, c->t, c->logits_tm + o * c->A, c->values_tm + o, c->actions_tm + o, true);
   if (rc)
     return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream)); // actions are now visible in pinned host memory
+  { // wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
+    volatile long long *tk = reinterpret_cast<volatile long long *>(c->h_actions + c->E);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    if (c->dbg_no_publish)
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    while (!c->dbg_no_publish && *tk != c->ticket) {
+      __builtin_ia32_pause();
+      if ((++spins & 1023u) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   if (actions_pinned)
     *actions_pinned = c->h_actions;
   return ALEPPO_OK;
@@ -507,8 +542,8 @@ static int do_push(aleppo_ctx *c, const uint8_t *frames, int kind, int location,
   if (rc)
     return rc;
   prof_begin(c, ALEPPO_K_INGEST);
-  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, c->d_start, c->obs, c->E, c->T + 1, c->t,
-                c->t + 1);
+  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, c->d_start, nullptr, c->obs, c->E, c->T + 1,
+                c->t, c->t + 1);
   prof_end(c, ALEPPO_K_INGEST);
   HIPCHK(c, hipGetLastError());
   return ALEPPO_OK;
@@ -524,9 +559,7 @@ static int do_record(aleppo_ctx *c, const float *rewards, const uint8_t *termina
   std::memcpy(c->h_step + 4 * (size_t)E, terminated, E);
   std::memcpy(c->h_step + 5 * (size_t)E, truncated, E);
   std::memcpy(c->h_step + 6 * (size_t)E, episode_start, E);
-  HIPCHK(c, hipMemcpyAsync(c->step_rec + (size_t)c->t * c->step_rec_bytes, c->h_step, (size_t)7 * E,
-                           hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
+  std::memcpy(c->h_rec + (size_t)c->t * c->step_rec_bytes, c->h_step, (size_t)7 * E); // uploaded at finish_rollout
   c->t++;
   return ALEPPO_OK;
 }
@@ -554,25 +587,32 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown frame kind");
   if (c->t >= c->T)
     return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
-  HIPCHK(c, hipEventSynchronize(c->ev_tmp)); // staging reuse guard (normally long finished: act() syncs)
-  // ONE upload: the packed step record lands in its final slot; ingest reads the start flags from it
+  // No per-slot upload: the scalars of rollout.cc:212-227 are packed into a pinned host record and reach the
+  // device in ONE copy at finish_rollout (only GAE reads them); the episode-start flags ingest needs now
+  // travel as a kernel-argument bitmask.
   const int E = c->E;
-  std::memcpy(c->h_step, rewards, (size_t)E * 4);
-  std::memcpy(c->h_step + 4 * (size_t)E, terminated, E);
-  std::memcpy(c->h_step + 5 * (size_t)E, truncated, E);
-  std::memcpy(c->h_step + 6 * (size_t)E, episode_start, E);
-  uint8_t *rec = c->step_rec + (size_t)c->t * c->step_rec_bytes;
-  HIPCHK(c, hipMemcpyAsync(rec, c->h_step, (size_t)7 * E, hipMemcpyHostToDevice, c->stream));
+  uint8_t *rec = c->h_rec + (size_t)c->t * c->step_rec_bytes;
+  std::memcpy(rec, rewards, (size_t)E * 4);
+  std::memcpy(rec + 4 * (size_t)E, terminated, E);
+  std::memcpy(rec + 5 * (size_t)E, truncated, E);
+  std::memcpy(rec + 6 * (size_t)E, episode_start, E);
+  StartBits sb{};
+  for (int e = 0; e < E; ++e)
+    if (episode_start[e])
+      sb.w[e >> 5] |= 1u << (e & 31);
   const uint8_t *df = nullptr;
+  if (location == ALEPPO_HOST)
+    HIPCHK(c, hipEventSynchronize(c->ev_tmp)); // frame staging reuse guard
   int rc = upload_frames(c, frames, kind, location, &df);
   if (rc)
     return rc;
   prof_begin(c, ALEPPO_K_INGEST);
-  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, rec + 6 * (size_t)E, c->obs, E, c->T + 1, c->t,
+  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, nullptr, &sb, c->obs, E, c->T + 1, c->t,
                 c->t + 1);
   prof_end(c, ALEPPO_K_INGEST);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
+  if (location == ALEPPO_HOST)
+    HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
   c->t++;
   return ALEPPO_OK;
 }
@@ -593,9 +633,10 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   // extra selector call on the post-rollout observation: its values bootstrap slot T-1, its sample is
   // discarded but advances the RNG stream like the reference (rollout.cc:268-270)
   int rc = do_act(c, noise, T, c->logits_tm + (size_t)T * E * A, c->values_tm + (size_t)T * E,
-                  c->actions_tm + (size_t)T * E);
+                  c->actions_tm + (size_t)T * E, false);
   if (rc)
     return rc;
+  HIPCHK(c, hipMemcpyAsync(c->step_rec, c->h_rec, c->step_rec_bytes * T, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_err, 0, 4, c->stream));
   prof_begin(c, ALEPPO_K_GAE);
   launch_gae(c->stream, c->step_rec, c->step_rec_bytes, c->values_tm, c->logits_tm, c->actions_tm, c->adv_n, c->ret_n,
@@ -961,10 +1002,13 @@ extern "C" int aleppo_comm_init(aleppo_ctx *c, const uint8_t id[ALEPPO_UNIQUE_ID
 // ------------------------------------------------------------------ profiling
 extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
   CHECK_CTX(c);
-  if (option != ALEPPO_OPT_GENERIC_CONV)
-    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  set_patch_kernels(value == 0);
+  if (option == ALEPPO_OPT_GENERIC_CONV)
+    set_patch_kernels(value == 0);
+  else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
+    c->dbg_no_publish = value != 0;
+  else
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
   return ALEPPO_OK;
 }
 extern "C" int aleppo_profile_enable(aleppo_ctx *c, int on) {

@@ -78,9 +78,14 @@ struct Ctx {
   uint8_t *d_frames = nullptr; // staging for host frames (max(E*2*210*160))
   float *d_noise = nullptr;    // [E][A]
   int *d_err = nullptr;        // device error word (flag overlap)
+  unsigned int *d_done = nullptr; // arrival counter of the head kernel's ticket publish
+  long long ticket = 0;        // last ticket published to h_actions[E]
   // pinned host staging
   int64_t *h_actions = nullptr; // [E]
-  uint8_t *h_step = nullptr;    // one step record
+  uint8_t *h_step = nullptr;    // one step record (aleppo_record_step path)
+  uint8_t *h_rec = nullptr;     // [T] step records filled by aleppo_step, uploaded once at finish_rollout
+  int rec_uploaded = 0;         // slots of h_rec already in device memory
+  int rec_direct = 0;           // slots written straight to the device by aleppo_record_step
   uint8_t *h_frames = nullptr;
   float *h_noise = nullptr;
   int *h_err = nullptr;
@@ -120,6 +125,7 @@ struct Ctx {
   long last_B = 0;
   // ---- profiling ----
   bool prof_on = false;
+  bool dbg_no_publish = false;
   ProfClass prof[ALEPPO_K_COUNT];
 };
 
@@ -132,12 +138,17 @@ int set_err(Ctx *c, int code, const std::string &msg);
   } while (0)
 
 // ------------------------------------------------------------------ kernel launchers (kernels.hip)
+constexpr int MAX_ENVS_PER_RANK = 8192;
+struct StartBits { // episode-start flags of one slot as a kernel argument (bit e of word e/32)
+  uint32_t w[MAX_ENVS_PER_RANK / 32];
+};
 void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
-                   uint32_t *obs, int E, int slots, int t_src, int t_dst);
+                   const StartBits *sbits, uint32_t *obs, int E, int slots, int t_src, int t_dst);
 void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, int dst);
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
                        const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
-                       float *values_t, int *actions_t, int64_t *pinned, int E, int H, int A);
+                       float *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
+                       int H, int A);
 void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
                 const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
                 int *err, int E, int T, int A, float gamma, float lambda);
@@ -212,6 +223,8 @@ void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float 
 void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns);
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns);
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns);
+void patch_act_convs(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
+                     const float *b2, const void *W3, const float *b3, void *a3, long ns);
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns);
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns);

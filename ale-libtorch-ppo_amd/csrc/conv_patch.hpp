@@ -256,6 +256,113 @@ template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(Patc
   }
 }
 
+// ================================================================================================
+// Acting path: conv1 -> conv2 -> conv3 of ONE sample per workgroup in a single launch.  The widened
+// 84x84x4 stack (56 KB), a1 (25.6 KB) and a2 (10.4 KB) live in LDS; only a3 (6 KB) goes back to HBM for
+// the batched fc GEMM.  At E_g = 128 envs this replaces three latency-bound launches per rollout slot.
+// ================================================================================================
+struct LConv1Full : LConv1Fwd {
+  static constexpr int IN_ELEMS = 84 * 84 * 4, PIX = 400, GPS = 1, GSTRIDE = 0;
+};
+struct ActConvParams {
+  const uint32_t *obs;
+  SampleMap map;
+  const bf16 *w1, *w2, *w3;
+  const float *b1, *b2, *b3;
+  bf16 *a3;
+  long ns;
+};
+
+// one forward phase out of LDS patch `pb`; writes 4 channels x 1 pixel per lane through `store(q, oc, v4)`
+template <class L, class Store>
+__device__ __forceinline__ void act_phase(const bf16 *pb, const bf16 *w, const float *bias, float scale, int wave,
+                                          int lane, Store store) {
+  constexpr int K = 32 * L::KS, NL = 8 / L::OG, NATOM = (L::PIX + 15) / 16, SEG = L::KW * L::C;
+  const int og = wave % L::OG, pl = wave / L::OG, fr = lane & 15, fg = lane >> 4;
+  u32x4 W[2][L::KS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int ks = 0; ks < L::KS; ++ks)
+      W[a][ks] = *reinterpret_cast<const u32x4 *>(w + (long)(og * 32 + a * 16 + fr) * K + ks * 32 + fg * 8);
+  const int oc0 = og * 32 + fg * 4;
+  float br[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      br[a][r] = bias[oc0 + a * 16 + r];
+  for (int atom = pl; atom < NATOM; atom += NL) {
+    const int q = atom * 16 + fr;
+    const bool qok = q < L::PIX;
+    const int oy = q / L::OW, ox = q - oy * L::OW;
+    const int base = qok ? ((oy * L::S) * L::IW + ox * L::S) * L::C + fg * 8 : fg * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < L::KS; ++ks) {
+      const int koff = ((ks * 32) / SEG) * (L::IW * L::C) + (ks * 32) % SEG;
+      const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
+      Atom<bf16>::mma(W[0][ks], b, acc0);
+      Atom<bf16>::mma(W[1][ks], b, acc1);
+    }
+    if (qok) {
+      store(q, oc0, pack4_bf16(fmaxf(acc0[0] * scale + br[0][0], 0.f), fmaxf(acc0[1] * scale + br[0][1], 0.f),
+                               fmaxf(acc0[2] * scale + br[0][2], 0.f), fmaxf(acc0[3] * scale + br[0][3], 0.f)));
+      store(q, oc0 + 16, pack4_bf16(fmaxf(acc1[0] * scale + br[1][0], 0.f), fmaxf(acc1[1] * scale + br[1][1], 0.f),
+                                    fmaxf(acc1[2] * scale + br[1][2], 0.f), fmaxf(acc1[3] * scale + br[1][3], 0.f)));
+    }
+  }
+}
+
+constexpr int ACT_X_ELEMS = 84 * 84 * 4, ACT_A1_ELEMS = 400 * 32, ACT_A2_ELEMS = 81 * 64;
+constexpr size_t ACT_SMEM = (size_t)(ACT_X_ELEMS + ACT_A1_ELEMS + ACT_A2_ELEMS) * 2;
+
+__global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  bf16 *sx = reinterpret_cast<bf16 *>(smem), *s1 = sx + ACT_X_ELEMS, *s2 = s1 + ACT_A1_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long n = blockIdx.x; n < P.ns; n += gridDim.x) {
+    { // stage + widen the packed u8 stack: 1764 16-byte vectors
+      const long nn = n + P.map.n0;
+      const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base;
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(P.obs + off);
+      auto pk = [](uint32_t lo, uint32_t hi) {
+        return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+      };
+      u32x4 R[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = tid + 512 * i;
+        R[i] = v < 1764 ? src[v] : zero16();
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = tid + 512 * i;
+        if (v < 1764) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t w0 = R[i][2 * d], w1 = R[i][2 * d + 1];
+            reinterpret_cast<u32x4 *>(sx)[2 * v + d] =
+                u32x4{pk(w0 & 255u, (w0 >> 8) & 255u), pk((w0 >> 16) & 255u, w0 >> 24),
+                      pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
+          }
+        }
+      }
+    }
+    __syncthreads();
+    act_phase<LConv1Full>(sx, P.w1, P.b1, 1.0f / 255.0f, wave, lane,
+                          [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s1 + q * 32 + oc) = v; });
+    __syncthreads();
+    act_phase<LConv2FwdSmall>(s1, P.w2, P.b2, 1.0f, wave, lane,
+                              [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s2 + q * 64 + oc) = v; });
+    __syncthreads();
+    bf16 *out = P.a3 + n * (long)(49 * 64);
+    act_phase<LConv3FwdSmall>(s2, P.w3, P.b3, 1.0f, wave, lane,
+                              [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(out + q * 64 + oc) = v; });
+    __syncthreads();
+  }
+}
+
 template <class L> constexpr size_t conv_patch_smem() {
   return (size_t)2 * ((L::SB * L::IN_ELEMS + 63) / 64 * 64) * 2;
 }

@@ -78,6 +78,18 @@ void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const vo
   launch_patch<LConv2Dgrad>(s, P);
 }
 
+void patch_act_convs(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
+                     const float *b2, const void *W3, const float *b3, void *a3, long ns) {
+  static bool once = false;
+  if (!once) {
+    allow_smem(act_conv_kernel, ACT_SMEM);
+    once = true;
+  }
+  ActConvParams P{obs, map, static_cast<const bf16 *>(W1), static_cast<const bf16 *>(W2), static_cast<const bf16 *>(W3),
+                  b1,  b2,  b3, static_cast<bf16 *>(a3), ns};
+  hipLaunchKernelGGL(act_conv_kernel, dim3((unsigned)std::min<long>(ns, num_cus())), dim3(512), ACT_SMEM, s, P);
+}
+
 template <class L> static int launch_wgrad(hipStream_t s, const WgradParams &P) {
   static bool once = false;
   constexpr size_t sm = conv_wgrad_patch_smem<L>();

@@ -3,9 +3,14 @@
 // weights [oc][(kh,kw,c)].  No vendor BLAS / MIOpen on this path.
 #include "common.hpp"
 #include "gemm.hpp"
+#include <cstdlib>
 
 namespace aleppo {
 
+static int tune(const char *name, int dflt) { // tile-shape A/B switches (read once)
+  const char *e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
 static inline dim3 grid2(long M, int BM, long N, int BN, int Z = 1) {
   return dim3((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN), (unsigned)Z);
 }
@@ -60,9 +65,21 @@ static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float
   if (ns <= 256) // acting batch: smaller M tile so more workgroups share the 3136-deep reduction
     hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 32, 32, 2, 2>), grid2(ns, 32, H, 32), dim3(256), 0, s, ap, bp,
                        ep, (int)ns, H, FC_IN);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(ns, 128, H, 64), dim3(256), 0, s, ap,
-                       bp, ep, (int)ns, H, FC_IN);
+  else {
+    static const int v = tune("ALEPPO_FC_FWD_TILE", 1);
+    if (v == 1)
+      hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 64, 64, 2, 2>), grid2(ns, 64, H, 64), dim3(256), 0, s, ap, bp,
+                         ep, (int)ns, H, FC_IN);
+    else if (v == 2)
+      hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 128, 2, 2>), grid2(ns, 128, H, 128), dim3(256), 0, s, ap,
+                         bp, ep, (int)ns, H, FC_IN);
+    else if (v == 3)
+      hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 64, 128, 2, 2>), grid2(ns, 64, H, 128), dim3(256), 0, s, ap,
+                         bp, ep, (int)ns, H, FC_IN);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(ns, 128, H, 64), dim3(256), 0, s, ap,
+                         bp, ep, (int)ns, H, FC_IN);
+  }
 }
 
 // acting-size fc (ns <= 256 rows): split the 3136-deep reduction over FC_SPLITS grid.z slices so 100s of
@@ -94,8 +111,16 @@ static void fc_dgrad_t(hipStream_t s, const void *dh, const void *WfcT, const vo
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(WfcT), H, 0};
   typename EP::P ep{static_cast<T *>(dz3), static_cast<const T *>(a3), FC_IN, 0};
-  hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(ns, 128, FC_IN, 64), dim3(256), 0, s, ap,
-                     bp, ep, (int)ns, FC_IN, H);
+  static const int v = tune("ALEPPO_FC_DGRAD_TILE", 1);
+  if (v == 1)
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 64, 64, 2, 2>), grid2(ns, 64, FC_IN, 64), dim3(256), 0, s, ap, bp,
+                       ep, (int)ns, FC_IN, H);
+  else if (v == 2)
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 128, 2, 2>), grid2(ns, 128, FC_IN, 128), dim3(256), 0, s,
+                       ap, bp, ep, (int)ns, FC_IN, H);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(ns, 128, FC_IN, 64), dim3(256), 0, s, ap,
+                       bp, ep, (int)ns, FC_IN, H);
 }
 template <class T>
 static void conv3_dgrad_t(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
@@ -145,13 +170,24 @@ template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const vo
   using AL = DenseLoader<T>;
   using BL = DenseLoader<T>;
   constexpr int KP = Atom<T>::KT;
-  const dim3 g = grid2(H, 64, FC_IN, 128);
-  const int S = 1; // 200 output tiles already fill the chip: no split-K, the "slab" IS the gradient tensor
+  static const int v = tune("ALEPPO_FC_WGRAD_TILE", 0);
+  const int S = 1; // the output tiles already fill the chip: no split-K, the "slab" IS the gradient tensor
   const int kc = chunk_for(ns, S, KP);
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
-  hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
-                     sb, H, FC_IN, (int)ns, kc, 1.0f);
+  if (v == 1) {
+    const dim3 g = grid2(H, 64, FC_IN, 64);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
+                       sb, H, FC_IN, (int)ns, kc, 1.0f);
+  } else if (v == 2) {
+    const dim3 g = grid2(H, 128, FC_IN, 64);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 128, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp,
+                       sw, sb, H, FC_IN, (int)ns, kc, 1.0f);
+  } else {
+    const dim3 g = grid2(H, 64, FC_IN, 128);
+    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp,
+                       sw, sb, H, FC_IN, (int)ns, kc, 1.0f);
+  }
   return S;
 }
 template <class T> static int conv3_wgrad_t(hipStream_t s, const void *dz3, const void *a2, float *sw, float *sb, long ns) {

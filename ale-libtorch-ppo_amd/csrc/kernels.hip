@@ -32,62 +32,71 @@ __device__ __forceinline__ float block_sum_256(float v, float *s4) {
 // The 4-frame stack of one pixel is ONE u32 (byte 0 = newest frame, Q11), so "shift + insert" is
 // (old << 8) | new and "broadcast on episode start" is new * 0x01010101.  The stack for slot t+1
 // is written straight into the rollout buffer; slot t is never copied again.
-// grid (7 bands of 12 output rows, E), 256 threads; a band needs exactly 30 raw rows per frame.
+// grid (28 x E) workgroups of 256 threads, one thread per output pixel.
 // ================================================================================================
 template <bool RAW>
-__global__ __launch_bounds__(512) void ingest_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ lut,
-                                                      const uint8_t *__restrict__ start, uint32_t *obs, int slots,
-                                                      int t_src, int t_dst) {
-  const int e = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) uint8_t sraw[2 * 30 * RAW_W];
+__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ lut,
+                                                      const uint8_t *__restrict__ start, StartBits sbits, uint32_t *obs,
+                                                      int slots, int t_src, int t_dst) {
+  // one thread per output pixel: every load of a thread (<= 18 raw bytes, the old packed pixel, the start flag)
+  // is independent and issued up front - one memory round trip, no staging barrier on the frame data; the
+  // 256-entry LUT sits in LDS.  A wave's 64 adjacent output pixels read ~122 adjacent raw bytes per row.
+  const int e = blockIdx.y, tid = threadIdx.x;
+  const int pix = blockIdx.x * 256 + tid;
   __shared__ uint8_t slut[256];
+  const bool live = pix < FRAME_PIX;
+  const int i = live ? pix / 84 : 0, j = live ? pix - i * 84 : 0;
+  uint32_t old = 0;
+  if (live)
+    old = obs[((size_t)e * slots + t_src) * FRAME_PIX + pix];
+  // episode-start flag: from the kernel-argument bitmask (no upload on the critical path) or from memory
+  const bool st = start ? start[e] != 0 : ((sbits.w[e >> 5] >> (e & 31)) & 1u) != 0;
+  uint32_t v = 0;
   if (RAW) {
-    for (int v = tid; v < 600; v += 512) { // 2 frames x 30 rows x 10 16-byte vectors, coalesced
-      const int f = v / 300, r = v - f * 300;
-      const u32x4 *src =
-          reinterpret_cast<const u32x4 *>(frames + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)band * 30 * RAW_W);
-      reinterpret_cast<u32x4 *>(sraw)[v] = src[r];
-    }
-    if (tid < 256)
-      slut[tid] = lut[tid];
-    __syncthreads();
-  }
-  const bool st = start[e] != 0;
-  const uint32_t *src = obs + ((size_t)e * slots + t_src) * FRAME_PIX;
-  uint32_t *dst = obs + ((size_t)e * slots + t_dst) * FRAME_PIX;
-  for (int pix = tid; pix < 12 * 84; pix += 512) {
-    const int il = pix / 84, j = pix - il * 84, i = band * 12 + il;
-    uint32_t v;
-    if (RAW) {
-      const int y0 = (i * RAW_H) / 84 - band * 30, y1 = ((i + 1) * RAW_H + 83) / 84 - band * 30;
-      const int x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84;
-      int best = 0;
+    const int y0 = (i * RAW_H) / 84, x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84; // 3 rows, 2-3 cols
+    const bool wide = (x1 - x0) == 3;
+    uint8_t rawb[2][3][3];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        int s = 0;
-        for (int y = y0; y < y1; ++y)
-          for (int x = x0; x < x1; ++x)
-            s += slut[sraw[(f * 30 + y) * RAW_W + x]];
-        // adaptive-average (area) mean in f32 like interpolate(mode=area), round-half-even to u8
-        const int q = (int)rintf((float)s / (float)((y1 - y0) * (x1 - x0)));
-        best = max(best, q);
+    for (int f = 0; f < 2; ++f) {
+      const uint8_t *src = frames + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)y0 * RAW_W + x0;
+#pragma unroll
+      for (int y = 0; y < 3; ++y) {
+        rawb[f][y][0] = live ? src[y * RAW_W] : 0;
+        rawb[f][y][1] = live ? src[y * RAW_W + 1] : 0;
+        rawb[f][y][2] = (live && wide) ? src[y * RAW_W + 2] : 0;
       }
-      v = (uint32_t)min(best, 255);
-    } else {
-      v = frames[(size_t)e * FRAME_PIX + i * 84 + j];
     }
-    const uint32_t old = src[i * 84 + j];
-    dst[i * 84 + j] = st ? v * 0x01010101u : ((old << 8) | v);
+    slut[tid] = lut[tid];
+    __syncthreads();
+    int best = 0;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      int s = 0;
+#pragma unroll
+      for (int y = 0; y < 3; ++y)
+        s += slut[rawb[f][y][0]] + slut[rawb[f][y][1]] + (wide ? slut[rawb[f][y][2]] : 0);
+      // adaptive-average (area) mean in f32 like interpolate(mode=area), round-half-even to u8
+      const int q = (int)rintf((float)s / (wide ? 9.0f : 6.0f));
+      best = max(best, q);
+    }
+    v = (uint32_t)min(best, 255);
+  } else if (live) {
+    v = frames[(size_t)e * FRAME_PIX + pix];
   }
+  if (live)
+    obs[((size_t)e * slots + t_dst) * FRAME_PIX + pix] = st ? v * 0x01010101u : ((old << 8) | v);
 }
 
 void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
-                   uint32_t *obs, int E, int slots, int t_src, int t_dst) {
+                   const StartBits *sbits, uint32_t *obs, int E, int slots, int t_src, int t_dst) {
+  const dim3 g((FRAME_PIX + 255) / 256, E);
+  StartBits sb{};
+  if (sbits)
+    sb = *sbits;
   if (raw)
-    hipLaunchKernelGGL(ingest_kernel<true>, dim3(7, E), dim3(512), 0, s, frames, lut, start, obs, slots, t_src, t_dst);
+    hipLaunchKernelGGL(ingest_kernel<true>, g, dim3(256), 0, s, frames, lut, start, sb, obs, slots, t_src, t_dst);
   else
-    hipLaunchKernelGGL(ingest_kernel<false>, dim3(7, E), dim3(512), 0, s, frames, lut, start, obs, slots, t_src,
-                       t_dst);
+    hipLaunchKernelGGL(ingest_kernel<false>, g, dim3(256), 0, s, frames, lut, start, sb, obs, slots, t_src, t_dst);
 }
 
 __global__ void copy_slot_kernel(uint32_t *obs, int slots, int src, int dst) {
@@ -122,94 +131,116 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   }
 }
 
-// h = sum of the fc split-K slices + fc bias, formed on the fly (all NSPLIT*8 loads of a lane are independent)
+// h = sum of the fc split-K slices + fc bias, formed on the fly (all NSPLIT*8 loads of a lane are independent).
+// Lane k < A owns action k (softmax term, noise, p/q); a wave arg-max picks the first maximum.
+// Hand-off to the host: actions go to pinned memory, then ONE ticket word is published after every wave's
+// stores are system-visible (fence + device counter, last wave publishes) - the host polls the ticket instead
+// of synchronising the stream, so PCIe write latency overlaps the host's next enqueue.
 template <int NSPLIT>
-__global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ hpart, int nsplit,
-                                                          const float *__restrict__ bfc, const float *__restrict__ Wh,
-                                                          const float *__restrict__ bh, const float *__restrict__ noise,
-                                                          uint64_t seed, uint64_t counter, float *logits_t,
-                                                          float *values_t, int *actions_t, int64_t *pinned, int E, int H,
-                                                          int A) {
-  __shared__ float sz[4][MAX_ACTIONS + 2];
+__global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ hpart, const float *__restrict__ bfc,
+                                                          const float *__restrict__ Wh, const float *__restrict__ bh,
+                                                          const float *__restrict__ noise, uint64_t seed,
+                                                          uint64_t counter, float *logits_t, float *values_t,
+                                                          int *actions_t, int64_t *pinned, unsigned int *done_ctr,
+                                                          long long ticket, int E, int H, int A) {
+  extern __shared__ float sWh[]; // [(A+1)][H] head weights: ONE parallel round trip for the whole workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 4 + wave;
-  if (e >= E)
-    return;
   float hv[8]; // H <= 512
+  float part[8][NSPLIT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 8; ++i) { // issue every split-K partial load first (independent)
     const int j = lane + 64 * i;
-    float v = 0.f;
-    if (j < H) {
-      float part[NSPLIT];
 #pragma unroll
-      for (int z = 0; z < NSPLIT; ++z)
-        part[z] = hpart[((size_t)z * E + e) * H + j];
-      v = bfc[j];
-#pragma unroll
-      for (int z = 0; z < NSPLIT; ++z)
-        v += part[z];
-    }
-    hv[i] = v;
+    for (int z = 0; z < NSPLIT; ++z)
+      part[i][z] = (e < E && j < H) ? hpart[((size_t)z * E + e) * H + j] : 0.f;
+    hv[i] = (e < E && j < H) ? bfc[j] : 0.f;
   }
-  (void)nsplit;
-  for (int a = 0; a <= A; ++a) {
-    float s = 0.f;
+  for (int k = threadIdx.x; k < (A + 1) * H; k += 256)
+    sWh[k] = Wh[k];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = lane + 64 * i;
-      if (j < H)
-        s += hv[i] * Wh[(size_t)a * H + j];
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int z = 0; z < NSPLIT; ++z)
+      hv[i] += part[i][z];
+  __syncthreads();
+  if (e < E) {
+    float zmine = 0.f; // lane a keeps logit a (a < A) / the value (a == A)
+    for (int a = 0; a <= A; ++a) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i;
+        if (j < H)
+          s += hv[i] * sWh[a * H + j];
+      }
+      s = wave_sum(s) + bh[a];
+      if (lane == a)
+        zmine = s;
     }
-    s = wave_sum(s);
-    if (lane == 0)
-      sz[wave][a] = s + bh[a];
-  }
-  if (lane == 0) {
-    const float *z = sz[wave];
-    float mx = z[0];
-    for (int k = 1; k < A; ++k)
-      mx = fmaxf(mx, z[k]);
-    float sum = 0.f;
-    for (int k = 0; k < A; ++k)
-      sum += expf(z[k] - mx);
-    int best = 0;
-    float bv = -1.f;
-    uint32_t c[4] = {0, 0, 0, 0};
-    for (int k = 0; k < A; ++k) {
-      const float p = expf(z[k] - mx) / sum;
-      float q;
+    const bool isact = lane < A;
+    float mx = isact ? zmine : -3.0e38f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64)); // A <= 18 < 32
+    const float ex = isact ? expf(zmine - mx) : 0.f;
+    float sum = ex;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+      sum += __shfl_xor(sum, o, 64);
+    float q = 1.f;
+    if (isact) {
       if (noise) {
-        q = noise[(size_t)e * A + k];
-      } else {
-        if ((k & 3) == 0) { // one Philox4x32-10 block serves four actions
-          c[0] = (uint32_t)counter;
-          c[1] = (uint32_t)(counter >> 32);
-          c[2] = (uint32_t)e;
-          c[3] = (uint32_t)(k >> 2);
-          philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        }
-        const float u = ((float)(c[k & 3] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0,1)
-        q = -logf(u);
+        q = noise[(size_t)e * A + lane];
+      } else { // Philox4x32-10 block (counter, env, lane/4): four actions share a block
+        uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)e, (uint32_t)(lane >> 2)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t w = (lane & 3) == 0 ? c[0] : (lane & 3) == 1 ? c[1] : (lane & 3) == 2 ? c[2] : c[3];
+        q = -logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f)); // u in (0,1)
       }
-      const float r = p / q;
-      if (r > bv) {
-        bv = r;
-        best = k;
-      }
-      logits_t[(size_t)e * A + k] = z[k];
     }
-    values_t[e] = z[A];
-    actions_t[e] = best;
-    pinned[e] = best;
+    float r = isact ? (ex / sum) / q : -1.f; // p_k / q_k (train.cc:374-375)
+    int best = lane;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { // arg-max, ties -> lowest index (first maximum wins)
+      const float ro = __shfl_xor(r, o, 64);
+      const int bo = __shfl_xor(best, o, 64);
+      if (ro > r || (ro == r && bo < best)) {
+        r = ro;
+        best = bo;
+      }
+    }
+    if (isact)
+      logits_t[(size_t)e * A + lane] = zmine;
+    if (lane == A)
+      values_t[e] = zmine;
+    if (lane == 0) {
+      actions_t[e] = best;
+      if (pinned)
+        pinned[e] = best;
+    }
+  }
+  if (done_ctr && pinned) { // publish: every storing wave makes its stores system-visible, the last arriver writes the ticket
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int prev = atomicAdd(done_ctr, 1u);
+      if (prev == gridDim.x - 1) {
+        *done_ctr = 0;
+        __threadfence_system();
+        *reinterpret_cast<volatile long long *>(pinned + E) = ticket;
+      }
+    }
   }
 }
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
                        const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
-                       float *values_t, int *actions_t, int64_t *pinned, int E, int H, int A) {
-  // nsplit is always FC_SPLITS on the acting path
-  hipLaunchKernelGGL(infer_head_kernel<FC_SPLITS>, dim3((E + 3) / 4), dim3(256), 0, s, hpart, nsplit, bfc, Wh, bh,
-                     noise, seed, counter, logits_t, values_t, actions_t, pinned, E, H, A);
+                       float *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
+                       int H, int A) {
+  (void)nsplit; // always FC_SPLITS on the acting path
+  hipLaunchKernelGGL(infer_head_kernel<FC_SPLITS>, dim3((E + 3) / 4), dim3(256), (size_t)(A + 1) * H * sizeof(float), s,
+                     hpart, bfc, Wh, bh, noise, seed, counter, logits_t, values_t, actions_t, pinned, done_ctr, ticket, E,
+                     H, A);
 }
 
 // ================================================================================================

@@ -108,9 +108,11 @@ def run(args):
         rew, te, tr, st = plans[plan_i]
         plan_i += 1
         t0 = time.perf_counter()
+        ra, ta, ua, sa = rew.ctypes.data, te.ctypes.data, tr.ctypes.data, st.ctypes.data
         for t in range(T):
-            eng.act()  # forward + sample; actions land in pinned host memory (an emulator would read them here)
-            eng.step(None, rew[t], te[t], tr[t], st[t], kind=pkg.FRAMES_RAW_PAIR, device_ptr=base_ptr + t * slot_bytes)
+            eng.act_fast()  # forward + sample; actions land in pinned host memory (an emulator reads them here)
+            eng.step_ptr(base_ptr + t * slot_bytes, pkg.DEVICE, pkg.FRAMES_RAW_PAIR, ra + 4 * E * t, ta + E * t,
+                         ua + E * t, sa + E * t)
         t1 = time.perf_counter()
         eng.finish_rollout()
         t2 = time.perf_counter()
@@ -156,10 +158,11 @@ def run(args):
     if rank == 0:
         def rollout_only():
             rew, te, tr, st = plans[-1]
+            ra, ta, ua, sa = rew.ctypes.data, te.ctypes.data, tr.ctypes.data, st.ctypes.data
             for t in range(T):
-                eng.act()
-                eng.step(None, rew[t], te[t], tr[t], st[t], kind=pkg.FRAMES_RAW_PAIR,
-                         device_ptr=base_ptr + t * slot_bytes)
+                eng.act_fast()
+                eng.step_ptr(base_ptr + t * slot_bytes, pkg.DEVICE, pkg.FRAMES_RAW_PAIR, ra + 4 * E * t, ta + E * t,
+                             ua + E * t, sa + E * t)
             eng.finish_rollout()
 
         torch.cuda.synchronize()

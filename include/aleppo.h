@@ -242,7 +242,10 @@ int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64
 int aleppo_profile_reset(aleppo_ctx *ctx);
 /* Process-wide tuning / A-B switches.  ALEPPO_OPT_GENERIC_CONV = 1: run the bf16 convolutions on the generic
  * gather-GEMM kernels instead of the sample-stationary ones (same math, used by the parity tests). */
-typedef enum { ALEPPO_OPT_GENERIC_CONV = 0 } aleppo_option;
+typedef enum {
+  ALEPPO_OPT_GENERIC_CONV = 0,
+  ALEPPO_OPT_DEBUG_NO_PUBLISH = 1 /* diagnosis only: the head kernel skips the pinned-memory hand-off */
+} aleppo_option;
 int aleppo_set_option(aleppo_ctx *ctx, int option, int value);
 /* Block until everything enqueued on ctx's streams has finished. */
 int aleppo_synchronize(aleppo_ctx *ctx);

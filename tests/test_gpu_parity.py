@@ -365,6 +365,36 @@ def test_rollout_protocol_vs_oracle(pkg, kind):
         params[:] = new  # the next rollout acts with the updated weights on both sides
 
 
+def test_bf16_acting_path_close_to_oracle(pkg):
+    """bf16 acting path (fused conv1-3 kernel, split-K fc, head): logits/values within the documented bf16
+    bound of the fp32 oracle; sampled actions bit-exact given ITS logits and the supplied noise"""
+    E, T, A, H = 37, 3, 6, 512
+    params = hf.fill_params(810, H, A)
+    eng = pkg.Engine(E, T, A, H, precision=pkg.BF16)
+    eng.load_params(params)
+    rng = np.random.default_rng(5)
+    obs_ref = np.zeros((E, 4, 84, 84), np.uint8)
+    start = np.ones(E, np.uint8)
+    noises, acts, obs_all = [], [], []
+    for t in range(T):
+        noise = rng.exponential(size=(E, A)).astype(np.float32)
+        acts.append(eng.act(noise).copy()); noises.append(noise); obs_all.append(obs_ref.copy())
+        frames = hf.hf_bytes(3000 + t, (E, 84, 84))
+        eng.step(frames, np.zeros(E, np.float32), np.zeros(E, np.uint8), np.zeros(E, np.uint8), start)
+        obs_ref = orc.update_observations(obs_ref, frames, start)
+        start = np.zeros(E, np.uint8)
+    eng.finish_rollout(rng.exponential(size=(E, A)).astype(np.float32))
+    logits = eng.read_batch("logits")
+    values = eng.read_batch("values")
+    np.testing.assert_array_equal(eng.read_batch("observations"), np.stack(obs_all, 1))
+    wl, wv = orc.net_forward(params, H, A, np.stack(obs_all, 1).reshape(E * T, 4, 84, 84))
+    np.testing.assert_allclose(logits.reshape(E * T, A), wl, atol=3e-2)
+    np.testing.assert_allclose(values.ravel(), wv, atol=3e-2)
+    want = orc.sample(orc.softmax(logits.reshape(E * T, A)), np.stack(noises, 1).reshape(E * T, A))
+    np.testing.assert_array_equal(np.stack(acts, 1).ravel(), want)
+    eng.close()
+
+
 def test_buffer_not_full_and_bad_minibatch_errors(pkg):
     eng = pkg.Engine(4, 4, 4, 32)
     with pytest.raises(pkg.AleppoError, match="Buffer is not full"):
