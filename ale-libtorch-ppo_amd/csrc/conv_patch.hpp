@@ -22,6 +22,9 @@ namespace aleppo {
 
 enum PatchMode { PM_FWD = 0, PM_DGRAD = 1 };
 
+// LDS pixel pitch CP: a patch pixel's C channels are followed by CP-C pad elements.  With the natural pitch
+// (64 or 128 B) the 16 lanes of an operand read (consecutive output pixels) fall on 2 bank groups - measured
+// 60-73 % of LDS cycles were conflict cycles; CP = 40 / 72 / 80 spreads them over 8-16 distinct 16/32-B slots.
 // ---- layer descriptors ---------------------------------------------------------------------------
 // forward: NHWC input [IH][IW][C], KHxKW window, stride S -> PIX = OHxOW output pixels, OUTC channels
 // conv1 works on HALF samples (output rows 0-9 / 10-19 <- input rows 0-43 / 40-83) so that two LDS buffers
@@ -31,19 +34,19 @@ struct LConv1Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
-                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4;
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4;
 };
 struct LConv2Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OUTC = 64, KS = 16,
-                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
+                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40;
 };
 struct LConv3Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
-                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
+                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 72;
 };
 // acting-size variants (ns <= 256): one sample per group so that every CU gets a workgroup
 struct LConv2FwdSmall : LConv2Fwd {
@@ -57,13 +60,13 @@ struct LConv3Dgrad {
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
-                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0;
+                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72;
 };
 struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
-                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0;
+                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 72;
 };
 
 struct PatchParams {
@@ -84,15 +87,18 @@ __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) 
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
 
-template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(PatchParams P) {
+template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch_kernel(PatchParams P) {
   using InT = typename L::InT;
   constexpr bool U8 = sizeof(InT) == 1;
   constexpr int K = 32 * L::KS;
-  constexpr int PATCH = L::IN_ELEMS;                         // bf16 elements per sample in LDS
-  constexpr int BUF_ELEMS = (L::SB * PATCH + 63) / 64 * 64;  // per buffer
+  constexpr int PATCH = L::IN_ELEMS;                         // source elements per unit
+  constexpr int LPATCH = PATCH / L::C * L::CP;               // bf16 elements per unit in LDS (padded pixel pitch)
+  constexpr int BUF_ELEMS = (L::SB * LPATCH + 63) / 64 * 64; // per buffer
   constexpr int SRC_VECS = L::SB * PATCH * (int)sizeof(InT) / 16; // 16-byte source vectors per group
-  constexpr int NV = (SRC_VECS + 511) / 512;
-  constexpr int NL = 8 / L::OG;                              // pixel lanes (waves sharing an oc group)
+  constexpr int NT = 64 * NW;                                // threads per workgroup
+  constexpr int NV = (SRC_VECS + NT - 1) / NT;
+  constexpr int NL = NW / L::OG;                             // pixel lanes (waves sharing an oc group)
+  static_assert(NW % L::OG == 0, "waves per workgroup must be a multiple of the channel groups");
   constexpr int NATOM = (L::SB * L::PIX + 15) / 16;
   static_assert((L::SB * PATCH * (int)sizeof(InT)) % 16 == 0, "group size");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -126,7 +132,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(Patc
     const long n0 = grp * L::SB;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int v = tid + 512 * i;
+      const int v = tid + NT * i;
       R[i] = zero16();
       if (v < SRC_VECS && grp < ngroups) {
         if constexpr (U8) { // SB == 1: one half of a packed stack per group, located through the slot map
@@ -146,7 +152,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(Patc
     bf16 *dst = sbuf + (size_t)buf * BUF_ELEMS;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int v = tid + 512 * i;
+      const int v = tid + NT * i;
       if (v < SRC_VECS) {
         if constexpr (U8) { // 16 bytes -> 16 bf16 (exact), two LDS vectors
           auto pk = [](uint32_t lo, uint32_t hi) {
@@ -165,8 +171,9 @@ template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(Patc
           }
           reinterpret_cast<u32x4 *>(dst)[2 * v] = o0;
           reinterpret_cast<u32x4 *>(dst)[2 * v + 1] = o1;
-        } else {
-          reinterpret_cast<u32x4 *>(dst)[v] = R[i];
+        } else { // vector v = 8 channels of pixel v / (C/8): padded pixel pitch CP
+          constexpr int VPP = L::C / 8;
+          *reinterpret_cast<u32x4 *>(dst + (v / VPP) * L::CP + (v % VPP) * 8) = R[i];
         }
       }
     }
@@ -189,13 +196,14 @@ template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(Patc
       long out_off;
       if constexpr (L::MODE == PM_FWD) {
         const int oy = p / L::OW, ox = p - oy * L::OW;
-        const int base = qok ? s * PATCH + ((oy * L::S) * L::IW + ox * L::S) * L::C + fg * 8 : fg * 8;
+        const int base = qok ? s * LPATCH + ((oy * L::S) * L::IW + ox * L::S) * L::CP + fg * 8 : fg * 8;
         constexpr int SEG = L::KW * L::C;
 #pragma unroll
         for (int ks = 0; ks < L::KS; ++ks) {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int koff = ((ks * 32) / SEG) * (L::IW * L::C) + (ks * 32) % SEG;
+          // k = 32ks + 8fg + j  ->  (kh, kw, c):  kh = 32ks / SEG, kw*C + c = 32ks % SEG (+ 8fg + j)
+          const int rem = (ks * 32) % SEG;
+          const int koff = L::C >= 32 ? (((ks * 32) / SEG) * L::IW + rem / L::C) * L::CP + rem % L::C
+                                      : ((ks * 32) / SEG) * (L::IW * L::CP) + rem;
           const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
           Atom<bf16>::mma(W[0][ks], b, acc0);
           Atom<bf16>::mma(W[1][ks], b, acc1);
@@ -203,17 +211,18 @@ template <class L> __global__ __launch_bounds__(512) void conv_patch_kernel(Patc
         out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
       } else {
         const int y = p / L::PW, x = p - y * L::PW;
-        const int base = s * PATCH + (y * L::OW + x) * L::OCK + fg * 8;
+        const int base = s * LPATCH + (y * L::OW + x) * L::CP + fg * 8;
         constexpr int KPT = L::OCK / 32; // k-steps per tap
 #pragma unroll
         for (int ks = 0; ks < L::KS; ++ks) {
           const int tap = ks / KPT, dy = tap / L::TW, dx = tap - dy * L::TW;
           const int sy = y - dy, sx = x - dx;
           const bool ok = qok && sy >= 0 && sy < L::OH && sx >= 0 && sx < L::OW;
-          const int off = base - (dy * L::OW + dx) * L::OCK + (ks % KPT) * 32;
-          u32x4 b = zero16();
-          if (ok)
-            b = *reinterpret_cast<const u32x4 *>(pb + off);
+          // branch-free: always read (clamped to an in-range address), then zero invalid taps -> the
+          // compiler can issue all KS LDS reads ahead of the MFMAs
+          const int off = ok ? base - (dy * L::OW + dx) * L::CP + (ks % KPT) * 32 : fg * 8;
+          u32x4 b = *reinterpret_cast<const u32x4 *>(pb + off);
+          b = ok ? b : zero16();
           Atom<bf16>::mma(W[0][ks], b, acc0);
           Atom<bf16>::mma(W[1][ks], b, acc1);
         }
@@ -296,11 +305,13 @@ __device__ __forceinline__ void act_phase(const bf16 *pb, const bf16 *w, const f
     const int q = atom * 16 + fr;
     const bool qok = q < L::PIX;
     const int oy = q / L::OW, ox = q - oy * L::OW;
-    const int base = qok ? ((oy * L::S) * L::IW + ox * L::S) * L::C + fg * 8 : fg * 8;
+    const int base = qok ? ((oy * L::S) * L::IW + ox * L::S) * L::CP + fg * 8 : fg * 8;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < L::KS; ++ks) {
-      const int koff = ((ks * 32) / SEG) * (L::IW * L::C) + (ks * 32) % SEG;
+      const int rem = (ks * 32) % SEG;
+      const int koff = L::C >= 32 ? (((ks * 32) / SEG) * L::IW + rem / L::C) * L::CP + rem % L::C
+                                  : ((ks * 32) / SEG) * (L::IW * L::CP) + rem;
       const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
       Atom<bf16>::mma(W[0][ks], b, acc0);
       Atom<bf16>::mma(W[1][ks], b, acc1);
@@ -314,7 +325,7 @@ __device__ __forceinline__ void act_phase(const bf16 *pb, const bf16 *w, const f
   }
 }
 
-constexpr int ACT_X_ELEMS = 84 * 84 * 4, ACT_A1_ELEMS = 400 * 32, ACT_A2_ELEMS = 81 * 64;
+constexpr int ACT_X_ELEMS = 84 * 84 * 4, ACT_A1_ELEMS = 400 * LConv2Fwd::CP, ACT_A2_ELEMS = 81 * LConv3Fwd::CP;
 constexpr size_t ACT_SMEM = (size_t)(ACT_X_ELEMS + ACT_A1_ELEMS + ACT_A2_ELEMS) * 2;
 
 __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
@@ -351,10 +362,10 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
     }
     __syncthreads();
     act_phase<LConv1Full>(sx, P.w1, P.b1, 1.0f / 255.0f, wave, lane,
-                          [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s1 + q * 32 + oc) = v; });
+                          [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s1 + q * LConv2Fwd::CP + oc) = v; });
     __syncthreads();
     act_phase<LConv2FwdSmall>(s1, P.w2, P.b2, 1.0f, wave, lane,
-                              [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s2 + q * 64 + oc) = v; });
+                              [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s2 + q * LConv3Fwd::CP + oc) = v; });
     __syncthreads();
     bf16 *out = P.a3 + n * (long)(49 * 64);
     act_phase<LConv3FwdSmall>(s2, P.w3, P.b3, 1.0f, wave, lane,
@@ -363,8 +374,22 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   }
 }
 
+// multi-sample variants for 4-wave workgroups (two or four independent workgroups per CU overlap one
+// workgroup's staging / barrier with another's MFMAs)
+struct LConv2FwdW4 : LConv2Fwd {
+  static constexpr int SB = 1;
+};
+struct LConv3FwdW4 : LConv3Fwd {
+  static constexpr int SB = 3;
+};
+struct LConv3DgradW4 : LConv3Dgrad {
+  static constexpr int SB = 4;
+};
+struct LConv2DgradW4 : LConv2Dgrad {
+  static constexpr int SB = 1;
+};
 template <class L> constexpr size_t conv_patch_smem() {
-  return (size_t)2 * ((L::SB * L::IN_ELEMS + 63) / 64 * 64) * 2;
+  return (size_t)2 * ((L::SB * (L::IN_ELEMS / L::C * L::CP) + 63) / 64 * 64) * 2;
 }
 
 // ================================================================================================
@@ -373,17 +398,17 @@ template <class L> constexpr size_t conv_patch_smem() {
 struct LConv1Wgrad { // half-sample units like LConv1Fwd
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OC = 32, NJ = 256,
-                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4; // wave: 2 oc x 2 of 16 j atoms
+                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4; // wave: 2 oc x 2 of 16 j atoms
 };
 struct LConv2Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OC = 64, NJ = 512, SB = 1,
-                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0; // wave: all 4 oc atoms x 4 of the 32 j atoms
+                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40; // wave: all 4 oc atoms x 4 of the 32 j atoms
 };
 struct LConv3Wgrad {
   using InT = bf16;
-  static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OC = 64, NJ = 576, SB = 4,
-                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0; // wave: 2 of 4 oc atoms x 9 of the 36 j atoms
+  static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OC = 64, NJ = 576, SB = 3,
+                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
 };
 
 struct WgradParams {
@@ -403,7 +428,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   constexpr int KPIX = L::SB * L::PIX;            // reduction length per group
   constexpr int KS = (KPIX + 31) / 32;            // atom-k steps per group (tail rows of dY are zero)
   constexpr int DYS = L::OC + 16;                 // dY tile row stride: (OC/2+8) dwords = 8 (mod 16)
-  constexpr int X_ELEMS = (L::SB * PATCH + 63) / 64 * 64;
+  constexpr int LPATCH = PATCH / L::C * L::CP;    // padded pixel pitch (conflict-free transposed reads)
+  constexpr int X_ELEMS = (L::SB * LPATCH + 63) / 64 * 64;
   constexpr int DY_ELEMS = KS * 32 * DYS;
   constexpr int BUF_ELEMS = X_ELEMS + DY_ELEMS;
   constexpr int XV = L::SB * PATCH * (int)sizeof(InT) / 16, NXV = (XV + 511) / 512;
@@ -437,13 +463,13 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
       int q = ks * 32 + r * 16 + 4 * lg + (li >> 2);
       q = min(q, KPIX - 1); // tail pixels: dY rows are zero, any finite in-range patch data will do
       const int s = q / L::PIX, p = q - s * L::PIX, oy = p / L::OW, ox = p - oy * L::OW;
-      pixoff[ks][r] = s * PATCH + ((oy * L::S) * L::IW + ox * L::S) * L::C;
+      pixoff[ks][r] = s * LPATCH + ((oy * L::S) * L::IW + ox * L::S) * L::CP;
     }
-  int joff[L::NI]; // column part: j = 16*(atom) + 4(li&3) -> (kh, inner)
+  int joff[L::NI]; // column part: j = 16*(atom) + 4(li&3) -> (kh, kw, c)
 #pragma unroll
   for (int j = 0; j < L::NI; ++j) {
     const int jj = (wn * L::NI + j) * 16 + 4 * (li & 3);
-    joff[j] = (jj / SEG) * (L::IW * L::C) + jj % SEG;
+    joff[j] = ((jj / SEG) * L::IW + (jj % SEG) / L::C) * L::CP + jj % L::C;
   }
 
   const long nunits = P.ns * L::GPS; // unit = sample or half sample; dY of unit u = rows [u*PIX, (u+1)*PIX)
@@ -497,7 +523,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
                       pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
           }
         } else {
-          reinterpret_cast<u32x4 *>(dx)[v] = RX[i];
+          constexpr int VPP = L::C / 8;
+          *reinterpret_cast<u32x4 *>(dx + (v / VPP) * L::CP + (v % VPP) * 8) = RX[i];
         }
       }
     }
@@ -581,7 +608,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
 
 template <class L> constexpr size_t conv_wgrad_patch_smem() {
   constexpr int KPIX = L::SB * L::PIX, KS = (KPIX + 31) / 32;
-  return (size_t)2 * (((L::SB * L::IN_ELEMS + 63) / 64 * 64) + KS * 32 * (L::OC + 16)) * 2;
+  return (size_t)2 * (((L::SB * (L::IN_ELEMS / L::C * L::CP) + 63) / 64 * 64) + KS * 32 * (L::OC + 16)) * 2;
 }
 
 } // namespace aleppo

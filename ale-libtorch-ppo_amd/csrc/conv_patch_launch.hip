@@ -34,48 +34,50 @@ template <class K> static void allow_smem(K kernel, size_t bytes) {
                             (int)bytes);
 }
 
-template <class L> static void launch_patch(hipStream_t s, const PatchParams &P) {
+// NW waves per workgroup, WPC persistent workgroups per CU
+template <class L, int NW, int WPC> static void launch_patch(hipStream_t s, const PatchParams &P) {
   static bool once = false;
   constexpr size_t sm = conv_patch_smem<L>();
+  static_assert(sm * WPC <= 160 * 1024, "LDS budget per CU");
   if (!once) {
-    allow_smem(conv_patch_kernel<L>, sm);
+    allow_smem(conv_patch_kernel<L, NW>, sm);
     once = true;
   }
   const long ngroups = (P.ns * L::GPS + L::SB - 1) / L::SB;
-  const int grid = (int)std::min<long>(ngroups, num_cus());
-  hipLaunchKernelGGL((conv_patch_kernel<L>), dim3(grid), dim3(512), sm, s, P);
+  const int grid = (int)std::min<long>(ngroups, (long)num_cus() * WPC);
+  hipLaunchKernelGGL((conv_patch_kernel<L, NW>), dim3(grid), dim3(64 * NW), sm, s, P);
 }
 
 void patch_conv1_fwd(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
                      long ns) {
   PatchParams P{obs, static_cast<const bf16 *>(W1), b1, nullptr, static_cast<bf16 *>(a1), ns, map, 1.0f / 255.0f};
-  launch_patch<LConv1Fwd>(s, P);
+  launch_patch<LConv1Fwd, 8, 2>(s, P);
 }
 void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
   PatchParams P{a1, static_cast<const bf16 *>(W2), b2, nullptr, static_cast<bf16 *>(a2), ns, SampleMap{1, 0, 0, 0, 0},
                 1.0f};
   if (ns <= 256)
-    launch_patch<LConv2FwdSmall>(s, P);
+    launch_patch<LConv2FwdSmall, 8, 1>(s, P);
   else
-    launch_patch<LConv2Fwd>(s, P);
+    launch_patch<LConv2FwdW4, 4, 2>(s, P);
 }
 void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
   PatchParams P{a2, static_cast<const bf16 *>(W3), b3, nullptr, static_cast<bf16 *>(a3), ns, SampleMap{1, 0, 0, 0, 0},
                 1.0f};
   if (ns <= 256)
-    launch_patch<LConv3FwdSmall>(s, P);
+    launch_patch<LConv3FwdSmall, 8, 1>(s, P);
   else
-    launch_patch<LConv3Fwd>(s, P);
+    launch_patch<LConv3FwdW4, 4, 2>(s, P);
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),
                 ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
-  launch_patch<LConv3Dgrad>(s, P);
+  launch_patch<LConv3DgradW4, 4, 2>(s, P);
 }
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
   PatchParams P{dz2, static_cast<const bf16 *>(W2d), nullptr, static_cast<const bf16 *>(a1), static_cast<bf16 *>(dz1),
                 ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
-  launch_patch<LConv2Dgrad>(s, P);
+  launch_patch<LConv2DgradW4, 4, 4>(s, P);
 }
 
 void patch_act_convs(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
