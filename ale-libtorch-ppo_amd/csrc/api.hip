@@ -742,15 +742,18 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
       prof_end(c, ALEPPO_K_FC_DGRAD);
       prof_begin(c, ALEPPO_K_FC_WGRAD);
-      (void)sWfc;
-      (void)sBfc;
-      fc_wgrad(s, prec, c->dh, c->a3, c->G + L.off[P_WFC], c->G + L.off[P_BFC], B, H); // single slice -> G directly
+      // split-K slabs (or, with one slice, straight into the gradient tensor)
+      const bool fc_direct = fc_wgrad_slices(prec, B) == 1;
+      const int Sfc = fc_wgrad(s, prec, c->dh, c->a3, fc_direct ? c->G + L.off[P_WFC] : sWfc,
+                               fc_direct ? c->G + L.off[P_BFC] : sBfc, B, H);
       prof_end(c, ALEPPO_K_FC_WGRAD);
       prof_begin(c, ALEPPO_K_REDUCE);
       {
-        const ReduceSeg segs[2] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
-                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]}};
-        launch_reduce_slabs(s, segs, 2, c->G);
+        const ReduceSeg segs[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
+                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]},
+                                   {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
+                                   {sBfc, Sfc, (long)H, (long)L.off[P_BFC]}};
+        launch_reduce_slabs(s, segs, fc_direct ? 2 : 4, c->G);
       }
       prof_end(c, ALEPPO_K_REDUCE);
       if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs

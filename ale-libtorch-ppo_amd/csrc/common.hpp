@@ -18,7 +18,7 @@ constexpr int FC_IN = 3136;
 constexpr int MAX_ACTIONS = 18;
 constexpr int FC_SPLITS = 7; // split-K slices of the acting-size fc forward (3136 = 7 * 448)
 // split-K slice caps of the wgrad slabs (gemm_launch.hip) and of the head kernel's partial slabs
-constexpr int MAXS_C1 = 256, MAXS_C2 = 256, MAXS_C3 = 256, MAXS_FC = 4, MAXS_HEAD = 256;
+constexpr int MAXS_C1 = 256, MAXS_C2 = 256, MAXS_C3 = 256, MAXS_FC = 8, MAXS_HEAD = 256;
 
 // ---- internal flat parameter layout (fp32 master, Adam moments, gradient share it) ----
 // order chosen so that what backward finishes FIRST is at the FRONT: bucket 0 = heads + fc can be
@@ -209,6 +209,7 @@ void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, cons
 void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns);
 // wgrads write split-K slabs; return the number of slices S used (slab holds S*[M*N] then bias S*[M])
 int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *slab_w, float *slab_b, long ns, int H);
+int fc_wgrad_slices(int prec, long ns); // number of split-K slices fc_wgrad will use for ns samples
 int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float *slab_w, float *slab_b, long ns);
 int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *slab_w, float *slab_b, long ns);
 int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *slab_w,

@@ -283,34 +283,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(typename AL::P ap, typenam
     for (int j = 0; j < NI; ++j)
       acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[AV], rb[BV];
+  const int fr = lane & 15, fg = lane >> 4;
+  // register prefetch TWO stages ahead (two register sets): a stage's global loads have a full
+  // stage of MFMAs plus the LDS phase of the previous one to land before they are written to LDS
+  u32x4 ra[2][AV], rb[2][BV];
   const int nk = (K + KT - 1) / KT;
-  auto gload = [&](int ks) {
+  auto gload = [&](int ks, int set) {
     const int k = ks * KT + kv * VE;
 #pragma unroll
     for (int i = 0; i < AV; ++i)
-      ra[i] = AL::load(ap, arow[i], k, K);
+      ra[set][i] = AL::load(ap, arow[i], k, K);
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      rb[i] = BL::load(bp, brow[i], k, K);
+      rb[set][i] = BL::load(bp, brow[i], k, K);
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, int set) {
 #pragma unroll
     for (int i = 0; i < AV; ++i)
-      sA[buf][(r0 + 32 * i) * LDS_ROW_V + kv] = ra[i];
+      sA[buf][(r0 + 32 * i) * LDS_ROW_V + kv] = ra[set][i];
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      sB[buf][(r0 + 32 * i) * LDS_ROW_V + kv] = rb[i];
+      sB[buf][(r0 + 32 * i) * LDS_ROW_V + kv] = rb[set][i];
   };
-
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  const int fr = lane & 15, fg = lane >> 4;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk)
-      gload(ks + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
       u32x4 fa[MI], fb[NI];
@@ -326,11 +321,131 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(typename AL::P ap, typenam
         for (int j = 0; j < NI; ++j)
           AT::mma(fa[i], fb[j], acc[i][j]);
     }
+  };
+
+  gload(0, 0);
+  if (nk > 1)
+    gload(1, 1);
+  swrite(0, 0);
+  __syncthreads();
+  // two stages per trip so that the register-set index is a compile-time constant
+  for (int ks = 0; ks < nk; ks += 2) {
+    if (ks + 2 < nk)
+      gload(ks + 2, 0);
+    compute(0);
     if (ks + 1 < nk)
-      swrite(buf ^ 1);
+      swrite(1, 1);
     __syncthreads();
+    if (ks + 1 < nk) {
+      if (ks + 3 < nk)
+        gload(ks + 3, 1);
+      compute(1);
+      if (ks + 2 < nk)
+        swrite(0, 0);
+      __syncthreads();
+    }
   }
   // C/D layout of the 16x16 atoms: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const typename EP::Row er = EP::row(ep, m0 + wm * WTM + i * 16 + fg * 4 + r, M);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        EP::store(ep, er, n0 + wn * WTN + j * 16 + fr, N, acc[i][j][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_dma: dense C = epi(A * B^T) with DIRECT-TO-LDS staging (global_load_lds_dwordx4).  The
+// register-staged kernel above tops out on the LDS *write* path (ds_write_b128 ~ 80 B/clk/CU: the same
+// fc GEMM reaches 64 % of the fp32 MFMA roof but only ~10 % of the bf16 one at identical bytes per
+// stage); the DMA writes LDS without VGPRs or ds_write.  Its destination is wave-uniform base + lane*16,
+// so LDS rows are the unpadded 128 B of a stage and bank conflicts are avoided by an XOR swizzle applied
+// on the SOURCE side: the 16-byte slot p of row r holds k-chunk p ^ (r & 7); fragment reads use the same
+// involution.  Two LDS buffers; the next stage's DMA is in flight during this stage's MFMAs; the
+// barrier's vmcnt(0) retires it.  Requires K % KT == 0 (rows beyond M / N are clamped and masked by the
+// epilogue).
+// ------------------------------------------------------------------------------------------------
+// CH = 16-byte chunks of k per row and stage (8 -> 128 B, 16 -> 256 B: half the barriers, twice the bytes in
+// flight per workgroup).
+template <class T, class EP, int BM, int BN, int WM, int WN, int CH = 8>
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const T *A, long lda, const T *B, long ldb, typename EP::P ep,
+                                                           int M, int N, int K) {
+  using AT = Atom<T>;
+  constexpr int VE = AT::VE, KT = VE * CH;
+  constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+  constexpr int RPP = 256 / CH; // rows covered by one pass of the 256 threads
+  constexpr int AV = BM / RPP, BV = BN / RPP;
+  static_assert(WM * WN == 4 && BM % RPP == 0 && BN % RPP == 0, "tile");
+  __shared__ __attribute__((aligned(16))) u32x4 sA[2][BM * CH];
+  __shared__ __attribute__((aligned(16))) u32x4 sB[2][BN * CH];
+  typedef __attribute__((address_space(1))) const void *gptr;
+  typedef __attribute__((address_space(3))) void *lptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  EP::set_z(ep, blockIdx.z);
+  // this thread moves slot (tid % CH) of rows (tid / CH) + RPP i: source chunk = slot ^ (row & 7)
+  const int slot = tid % CH, r0 = tid / CH;
+  const T *asrc[AV], *bsrc[BV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int r = r0 + RPP * i;
+    asrc[i] = A + (long)min(m0 + r, M - 1) * lda + ((slot ^ (r & 7)) * VE);
+  }
+#pragma unroll
+  for (int i = 0; i < BV; ++i) {
+    const int r = r0 + RPP * i;
+    bsrc[i] = B + (long)min(n0 + r, N - 1) * ldb + ((slot ^ (r & 7)) * VE);
+  }
+  auto stage = [&](int buf, int ks) {
+    const int k = ks * KT;
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr)(asrc[i] + k), (lptr)&sA[buf][wave * 64 + 256 * i], 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr)(bsrc[i] + k), (lptr)&sB[buf][wave * 64 + 256 * i], 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  const int nk = K / KT;
+  stage(0, 0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk)
+      stage(buf ^ 1, ks + 1);
+#pragma unroll
+    for (int kc = 0; kc < CH / 4; ++kc) {
+      u32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * WTM + i * 16 + fr;
+        fa[i] = sA[buf][r * CH + ((kc * 4 + fg) ^ (r & 7))];
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int r = wn * WTN + j * 16 + fr;
+        fb[j] = sB[buf][r * CH + ((kc * 4 + fg) ^ (r & 7))];
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          AT::mma(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll

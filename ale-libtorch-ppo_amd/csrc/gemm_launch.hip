@@ -3,6 +3,7 @@
 // weights [oc][(kh,kw,c)].  No vendor BLAS / MIOpen on this path.
 #include "common.hpp"
 #include "gemm.hpp"
+#include <algorithm>
 #include <cstdlib>
 
 namespace aleppo {
@@ -65,7 +66,25 @@ static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float
   if (ns <= 256) // acting batch: smaller M tile so more workgroups share the 3136-deep reduction
     hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 32, 32, 2, 2>), grid2(ns, 32, H, 32), dim3(256), 0, s, ap, bp,
                        ep, (int)ns, H, FC_IN);
-  else {
+  else if (tune("ALEPPO_FC_DMA", 1) && FC_IN % Atom<T>::KT == 0) {
+    static const int v = tune("ALEPPO_FC_FWD_TILE", 1);
+    const T *a = static_cast<const T *>(a3), *b = static_cast<const T *>(Wfc);
+    if (v == 3 && FC_IN % (2 * Atom<T>::KT) == 0)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 64, 64, 2, 2, 16>), grid2(ns, 64, H, 64), dim3(256), 0, s, a, FC_IN,
+                         b, FC_IN, ep, (int)ns, H, FC_IN);
+    else if (v == 4 && FC_IN % (2 * Atom<T>::KT) == 0)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 128, 64, 2, 2, 16>), grid2(ns, 128, H, 64), dim3(256), 0, s, a,
+                         FC_IN, b, FC_IN, ep, (int)ns, H, FC_IN);
+    else if (v == 1)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 64, 64, 2, 2>), grid2(ns, 64, H, 64), dim3(256), 0, s, a, FC_IN, b,
+                         FC_IN, ep, (int)ns, H, FC_IN);
+    else if (v == 2)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 128, 128, 2, 2>), grid2(ns, 128, H, 128), dim3(256), 0, s, a,
+                         FC_IN, b, FC_IN, ep, (int)ns, H, FC_IN);
+    else
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 128, 64, 2, 2>), grid2(ns, 128, H, 64), dim3(256), 0, s, a, FC_IN,
+                         b, FC_IN, ep, (int)ns, H, FC_IN);
+  } else {
     static const int v = tune("ALEPPO_FC_FWD_TILE", 1);
     if (v == 1)
       hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 64, 64, 2, 2>), grid2(ns, 64, H, 64), dim3(256), 0, s, ap, bp,
@@ -112,6 +131,25 @@ static void fc_dgrad_t(hipStream_t s, const void *dh, const void *WfcT, const vo
   typename BL::P bp{static_cast<const T *>(WfcT), H, 0};
   typename EP::P ep{static_cast<T *>(dz3), static_cast<const T *>(a3), FC_IN, 0};
   static const int v = tune("ALEPPO_FC_DGRAD_TILE", 1);
+  if (tune("ALEPPO_FC_DMA", 1) && H % Atom<T>::KT == 0) {
+    const T *a = static_cast<const T *>(dh), *b = static_cast<const T *>(WfcT);
+    if (v == 3)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 64, 64, 2, 2, 16>), grid2(ns, 64, FC_IN, 64), dim3(256), 0, s, a, H,
+                         b, H, ep, (int)ns, FC_IN, H);
+    else if (v == 4)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 128, 64, 2, 2, 16>), grid2(ns, 128, FC_IN, 64), dim3(256), 0, s, a,
+                         H, b, H, ep, (int)ns, FC_IN, H);
+    else if (v == 2)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 128, 128, 2, 2>), grid2(ns, 128, FC_IN, 128), dim3(256), 0, s, a,
+                         H, b, H, ep, (int)ns, FC_IN, H);
+    else if (v == 0)
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 128, 64, 2, 2>), grid2(ns, 128, FC_IN, 64), dim3(256), 0, s, a, H,
+                         b, H, ep, (int)ns, FC_IN, H);
+    else
+      hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 64, 64, 2, 2>), grid2(ns, 64, FC_IN, 64), dim3(256), 0, s, a, H, b,
+                         H, ep, (int)ns, FC_IN, H);
+    return;
+  }
   if (v == 1)
     hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 64, 64, 2, 2>), grid2(ns, 64, FC_IN, 64), dim3(256), 0, s, ap, bp,
                        ep, (int)ns, FC_IN, H);
@@ -171,7 +209,9 @@ template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const vo
   using BL = DenseLoader<T>;
   constexpr int KP = Atom<T>::KT;
   static const int v = tune("ALEPPO_FC_WGRAD_TILE", 0);
-  const int S = 1; // the output tiles already fill the chip: no split-K, the "slab" IS the gradient tensor
+  static const int smax = tune("ALEPPO_FC_WGRAD_SPLIT", 4);
+  // S == 1: the "slab" IS the gradient tensor (caller passes G); S > 1: split-K slabs reduced by the caller
+  const int S = (int)std::max<long>(1, std::min<long>(std::min(smax, MAXS_FC), ns / (4 * KP)));
   const int kc = chunk_for(ns, S, KP);
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
@@ -276,6 +316,11 @@ void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, cons
   if (prec == ALEPPO_BF16 && use_patch_kernels())
     return patch_conv2_dgrad(s, dz2, W2d, a1, dz1, ns);
   DISPATCH(prec, conv2_dgrad_t<float>(s, dz2, W2d, a1, dz1, ns), conv2_dgrad_t<bf16>(s, dz2, W2d, a1, dz1, ns));
+}
+int fc_wgrad_slices(int prec, long ns) {
+  static const int smax = tune("ALEPPO_FC_WGRAD_SPLIT", 4);
+  const int KP = prec == ALEPPO_BF16 ? Atom<bf16>::KT : Atom<float>::KT;
+  return (int)std::max<long>(1, std::min<long>(std::min(smax, MAXS_FC), ns / (4 * KP)));
 }
 int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *sw, float *sb, long ns, int H) {
   if (prec == ALEPPO_BF16)
