@@ -1,0 +1,650 @@
+// train - C++ trainer shell over libaleppo.so (C ABI only; no libtorch, no HIP headers).
+//
+// Keeps the command line and the configs/*.yaml keys of the reference trainer
+//   train <rom> <log path> <video dir> <group> <config.yaml> [profile]          (src/bin/train.cc:323-335)
+// and re-hosts what main() and Rollout's HOST half do around the hot path:
+//   * Config / load_config with the reference's keys and defaults           (src/bin/train.cc:33-63,108-136)
+//   * worker threads stepping environments, fed by an index queue           (src/ai/rollout.cc:280-328, queue.h)
+//     - actions are read from the pinned buffer aleppo_act returns instead of tensor.item()  (rollout.cc:312-313)
+//   * the slot protocol: episode-start slots, stale rewards, flag bookkeeping, episode / game statistics,
+//     total_steps counting only non-start slots                              (src/ai/rollout.cc:204-267)
+//   * warm rollout before the loop, linear lr anneal, "Rollout i of N", scalar logging
+//                                                                            (src/bin/train.cc:391-458,163-210)
+//   * orthogonal init with gains sqrt(2) / 0.01 / 1, zero biases            (src/bin/train.cc:212-253)
+//   * a TensorBoard event file (TFRecord + hand-encoded protobuf; scalars and histograms)
+// ALE is not available in this build environment (no headers, no ROMs): the emulator behind the
+// VirtualEnvironment-like interface is a deterministic synthetic Atari-shaped game (84x84 gray frames,
+// 5 lives, reward on "brick hits", terminal on life loss like EpisodeLife, truncation at max_steps /
+// max_return).  The rom argument is accepted and recorded but not opened.
+// New OPTIONAL yaml keys (defaults reproduce the reference): precision: fp32|bf16, advantage_norm: false,
+// action_size (honoured here; the reference hard-codes 4, Q4), seed.
+#include "../include/aleppo.h"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <mutex>
+#include <numeric>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+// ------------------------------------------------------------------ config
+struct Config {
+  size_t total_environments = 512, hidden_size = 512, action_size = 4, horizon = 128, max_steps = 108000,
+         frame_stack = 4;
+  double learning_rate = 2.5e-4;
+  float clip_param = 0.1f, value_loss_coef = 0.5f, entropy_coef = 0.01f;
+  long num_epochs = 1, mini_batch_size = 2048, num_mini_batches = 32;
+  float gae_discount = 0.99f, gae_lambda = 0.95f, max_gradient_norm = 0.5f;
+  size_t num_rollouts = 7000, num_workers = 16, worker_batch_size = 32, frame_skip = 4;
+  float max_return = -1.0f;
+  bool record_observation = false, record_video = false, cuda_graph = false, deterministic = false;
+  // extensions
+  std::string precision = "fp32";
+  bool advantage_norm = false;
+  uint64_t seed = 42;
+};
+
+static std::string trim(const std::string &s) {
+  const size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+  return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+}
+// flat "key: value" YAML (what configs/*.yaml use): comments, blank lines, scalars
+static std::map<std::string, std::string> parse_yaml(const std::string &path) {
+  std::ifstream f(path);
+  if (!f)
+    throw std::runtime_error("cannot open config: " + path);
+  std::map<std::string, std::string> kv;
+  std::string line;
+  while (std::getline(f, line)) {
+    const size_t h = line.find('#');
+    if (h != std::string::npos)
+      line = line.substr(0, h);
+    const size_t c = line.find(':');
+    if (c == std::string::npos)
+      continue;
+    const std::string k = trim(line.substr(0, c)), v = trim(line.substr(c + 1));
+    if (!k.empty() && !v.empty())
+      kv[k] = v;
+  }
+  return kv;
+}
+template <class T> static T as(const std::map<std::string, std::string> &kv, const char *k, T dflt) {
+  auto it = kv.find(k);
+  if (it == kv.end())
+    return dflt;
+  std::istringstream ss(it->second);
+  T v;
+  ss >> v;
+  if (ss.fail())
+    throw std::runtime_error(std::string("bad value for ") + k);
+  return v;
+}
+static bool as_bool(const std::map<std::string, std::string> &kv, const char *k, bool dflt) {
+  auto it = kv.find(k);
+  if (it == kv.end())
+    return dflt;
+  return it->second == "true" || it->second == "True" || it->second == "1" || it->second == "yes";
+}
+static Config load_config(const std::string &path) { // keys / defaults of src/bin/train.cc:108-136
+  const auto kv = parse_yaml(path);
+  Config c;
+  c.total_environments = as<size_t>(kv, "total_environments", 512);
+  c.hidden_size = as<size_t>(kv, "hidden_size", 512);
+  c.action_size = as<size_t>(kv, "action_size", 4);
+  c.horizon = as<size_t>(kv, "horizon", 128);
+  c.max_steps = as<size_t>(kv, "max_steps", 108000);
+  c.frame_stack = as<size_t>(kv, "frame_stack", 4);
+  c.learning_rate = as<double>(kv, "learning_rate", 2.5e-4);
+  c.clip_param = as<float>(kv, "clip_param", 0.1f);
+  c.value_loss_coef = as<float>(kv, "value_loss_coef", 0.5f);
+  c.entropy_coef = as<float>(kv, "entropy_coef", 0.01f);
+  c.num_epochs = as<long>(kv, "num_epochs", 1);
+  c.mini_batch_size = as<long>(kv, "mini_batch_size", 2048);
+  c.num_mini_batches = as<long>(kv, "num_mini_batches", 32);
+  c.gae_discount = as<float>(kv, "gae_discount", 0.99f);
+  c.gae_lambda = as<float>(kv, "gae_lambda", 0.95f);
+  c.max_gradient_norm = as<float>(kv, "max_gradient_norm", 0.5f);
+  c.num_rollouts = as<size_t>(kv, "num_rollouts", 7000);
+  c.num_workers = as<size_t>(kv, "num_workers", 16);
+  c.worker_batch_size = as<size_t>(kv, "worker_batch_size", 32);
+  c.frame_skip = as<size_t>(kv, "frame_skip", 4);
+  c.max_return = as<float>(kv, "max_return", -1.0f);
+  c.record_observation = as_bool(kv, "record_observation", false);
+  c.record_video = as_bool(kv, "record_video", false);
+  c.cuda_graph = as_bool(kv, "cuda_graph", false);
+  c.deterministic = as_bool(kv, "deterministic", false);
+  c.precision = as<std::string>(kv, "precision", "fp32");
+  c.advantage_norm = as_bool(kv, "advantage_norm", false);
+  c.seed = as<uint64_t>(kv, "seed", 42);
+  return c;
+}
+
+// ------------------------------------------------------------------ synthetic emulator (stands in for the ALE wrapper chain)
+struct StepOut {
+  float reward = 0.f;
+  bool terminated = false, truncated = false, game_over = false;
+};
+class SyntheticAtari {
+public:
+  SyntheticAtari(uint64_t seed, size_t max_steps, float max_return, size_t actions)
+      : rng_(seed * 0x9E3779B97F4A7C15ull + 12345), max_steps_(max_steps), max_return_(max_return), actions_(actions) {}
+  // FireReset / EpisodeLife semantics: a full reset only after game over, otherwise continue with the next life
+  void reset(uint8_t *frame) {
+    if (lives_ == 0) {
+      lives_ = 5;
+      steps_ = 0;
+      episode_return_ = 0.f;
+      bricks_ = 0;
+    }
+    ball_x_ = 42;
+    ball_y_ = 60;
+    dx_ = (next() & 1) ? 1 : -1;
+    dy_ = -1;
+    render(frame);
+  }
+  StepOut step(int action, uint8_t *frame) {
+    StepOut o;
+    paddle_ += (action == 2 ? 3 : action == 3 ? -3 : 0); // NOOP FIRE RIGHT LEFT like Breakout's minimal set
+    paddle_ = std::clamp(paddle_, 4, 79);
+    for (int k = 0; k < 4; ++k) { // frame_skip emulator frames per agent step
+      ball_x_ += dx_ * 2;
+      ball_y_ += dy_ * 2;
+      if (ball_x_ <= 1 || ball_x_ >= 82)
+        dx_ = -dx_;
+      if (ball_y_ <= 20) { // brick row
+        dy_ = 1;
+        o.reward += (float)(1 + 3 * (bricks_ % 3 == 2));
+        ++bricks_;
+      }
+      if (ball_y_ >= 78) {
+        if (std::abs(ball_x_ - paddle_) <= 8 || (next() % 3) == 0)
+          dy_ = -1;
+        else { // life lost -> EpisodeLife reports a terminal
+          --lives_;
+          o.terminated = true;
+          break;
+        }
+      }
+    }
+    steps_ += 4;
+    episode_return_ += o.reward;
+    o.game_over = lives_ == 0;
+    if (!o.terminated && (steps_ >= max_steps_ || (max_return_ > 0 && episode_return_ >= max_return_))) {
+      o.truncated = true; // ALE max_num_frames_per_episode / TruncateOnEpisodeReturn
+      lives_ = 0;
+      o.game_over = true;
+    }
+    render(frame);
+    (void)actions_;
+    return o;
+  }
+
+private:
+  uint64_t next() {
+    rng_ ^= rng_ << 13;
+    rng_ ^= rng_ >> 7;
+    rng_ ^= rng_ << 17;
+    return rng_;
+  }
+  void render(uint8_t *f) const {
+    std::memset(f, 0, 84 * 84);
+    for (int y = 8; y < 20; ++y)
+      for (int x = 0; x < 84; ++x)
+        f[y * 84 + x] = (uint8_t)(((x / 6 + y / 3 + bricks_) % 4) * 50 + 60);
+    for (int x = paddle_ - 6; x <= paddle_ + 6; ++x)
+      if (x >= 0 && x < 84)
+        f[80 * 84 + x] = f[81 * 84 + x] = 200;
+    for (int y = ball_y_; y < ball_y_ + 2; ++y)
+      for (int x = ball_x_; x < ball_x_ + 2; ++x)
+        if (x >= 0 && x < 84 && y >= 0 && y < 84)
+          f[y * 84 + x] = 236;
+  }
+  uint64_t rng_;
+  size_t max_steps_;
+  float max_return_;
+  size_t actions_;
+  int lives_ = 0, paddle_ = 42, ball_x_ = 42, ball_y_ = 60, dx_ = 1, dy_ = -1, bricks_ = 0;
+  size_t steps_ = 0;
+  float episode_return_ = 0.f;
+};
+
+// ------------------------------------------------------------------ worker pool (std::thread + index queue, rollout.cc:280-297)
+class WorkerPool {
+public:
+  WorkerPool(size_t n, std::function<void(size_t)> fn) : fn_(std::move(fn)) {
+    for (size_t i = 0; i < n; ++i)
+      threads_.emplace_back([this] { loop(); });
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_)
+      t.join();
+  }
+  void run_all(size_t count) { // push indices 0..count-1, wait until all are done (step_all)
+    {
+      std::lock_guard<std::mutex> l(m_);
+      next_ = 0;
+      end_ = count;
+      done_ = 0;
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> l(m_);
+    done_cv_.wait(l, [&] { return done_ == end_; });
+  }
+
+private:
+  void loop() {
+    for (;;) {
+      size_t i;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || next_ < end_; });
+        if (stop_)
+          return;
+        i = next_++;
+      }
+      fn_(i);
+      {
+        std::lock_guard<std::mutex> l(m_);
+        if (++done_ == end_)
+          done_cv_.notify_all();
+      }
+    }
+  }
+  std::function<void(size_t)> fn_;
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  size_t next_ = 0, end_ = 0, done_ = 0;
+  bool stop_ = false;
+};
+
+// ------------------------------------------------------------------ TensorBoard event file (TFRecord + protobuf by hand)
+static uint32_t crc32c(const uint8_t *p, size_t n) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k)
+        c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[i] = c;
+    }
+    init = true;
+  }
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; ++i)
+    c = table[(c ^ p[i]) & 255] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+static uint32_t masked_crc(const uint8_t *p, size_t n) {
+  const uint32_t c = crc32c(p, n);
+  return ((c >> 15) | (c << 17)) + 0xa282ead8u;
+}
+struct Pb { // minimal protobuf encoder
+  std::string b;
+  void varint(uint64_t v) {
+    while (v >= 128) {
+      b.push_back((char)(v | 128));
+      v >>= 7;
+    }
+    b.push_back((char)v);
+  }
+  void key(int field, int wire) { varint(((uint64_t)field << 3) | wire); }
+  void f64(int field, double v) {
+    key(field, 1);
+    b.append(reinterpret_cast<const char *>(&v), 8);
+  }
+  void f32(int field, float v) {
+    key(field, 5);
+    b.append(reinterpret_cast<const char *>(&v), 4);
+  }
+  void i64(int field, int64_t v) {
+    key(field, 0);
+    varint((uint64_t)v);
+  }
+  void bytes(int field, const std::string &s) {
+    key(field, 2);
+    varint(s.size());
+    b += s;
+  }
+  void packed_f64(int field, const std::vector<double> &v) {
+    key(field, 2);
+    varint(v.size() * 8);
+    b.append(reinterpret_cast<const char *>(v.data()), v.size() * 8);
+  }
+};
+class EventWriter {
+public:
+  explicit EventWriter(const std::string &path) : f_(path, std::ios::binary) {
+    if (!f_)
+      throw std::runtime_error("cannot open event file: " + path);
+    Pb e;
+    e.f64(1, now());
+    e.bytes(3, "brain.Event:2"); // file_version
+    record(e.b);
+  }
+  void add_scalar(const std::string &tag, int64_t step, float value) {
+    Pb v;
+    v.bytes(1, tag);
+    v.f32(2, value);
+    Pb s;
+    s.bytes(1, v.b);
+    Pb e;
+    e.f64(1, now());
+    e.i64(2, step);
+    e.bytes(5, s.b);
+    record(e.b);
+  }
+  void add_histogram(const std::string &tag, int64_t step, const std::vector<float> &x) {
+    if (x.empty())
+      return;
+    double mn = x[0], mx = x[0], sum = 0, sq = 0;
+    for (float v : x) {
+      mn = std::min<double>(mn, v);
+      mx = std::max<double>(mx, v);
+      sum += v;
+      sq += (double)v * v;
+    }
+    const int nb = 30;
+    std::vector<double> limits(nb), counts(nb, 0.0);
+    const double w = (mx - mn) / nb > 0 ? (mx - mn) / nb : 1.0;
+    for (int i = 0; i < nb; ++i)
+      limits[i] = mn + w * (i + 1);
+    for (float v : x)
+      counts[std::min(nb - 1, (int)((v - mn) / w))] += 1.0;
+    Pb h; // HistogramProto: min=1 max=2 num=3 sum=4 sum_squares=5 bucket_limit=6 bucket=7
+    h.f64(1, mn);
+    h.f64(2, mx);
+    h.f64(3, (double)x.size());
+    h.f64(4, sum);
+    h.f64(5, sq);
+    h.packed_f64(6, limits);
+    h.packed_f64(7, counts);
+    Pb v;
+    v.bytes(1, tag);
+    v.bytes(5, h.b); // Summary.Value.histo
+    Pb s;
+    s.bytes(1, v.b);
+    Pb e;
+    e.f64(1, now());
+    e.i64(2, step);
+    e.bytes(5, s.b);
+    record(e.b);
+  }
+  void flush() { f_.flush(); }
+
+private:
+  static double now() { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+  void record(const std::string &data) {
+    const uint64_t len = data.size();
+    const uint32_t c1 = masked_crc(reinterpret_cast<const uint8_t *>(&len), 8);
+    const uint32_t c2 = masked_crc(reinterpret_cast<const uint8_t *>(data.data()), data.size());
+    f_.write(reinterpret_cast<const char *>(&len), 8);
+    f_.write(reinterpret_cast<const char *>(&c1), 4);
+    f_.write(data.data(), (std::streamsize)data.size());
+    f_.write(reinterpret_cast<const char *>(&c2), 4);
+  }
+  std::ofstream f_;
+};
+
+// ------------------------------------------------------------------ orthogonal init (train.cc:212-228)
+// rows x cols matrix of N(0,1), orthonormalised (modified Gram-Schmidt on the smaller dimension), times gain
+static void orthogonal(float *w, size_t rows, size_t cols, double gain, std::mt19937_64 &g) {
+  std::normal_distribution<double> nd(0.0, 1.0);
+  const bool tr = rows < cols;
+  const size_t R = tr ? cols : rows, C = tr ? rows : cols; // R >= C: orthonormal columns
+  std::vector<double> a(R * C);
+  for (auto &v : a)
+    v = nd(g);
+  for (size_t j = 0; j < C; ++j) {
+    for (size_t k = 0; k < j; ++k) {
+      double dot = 0;
+      for (size_t i = 0; i < R; ++i)
+        dot += a[i * C + j] * a[i * C + k];
+      for (size_t i = 0; i < R; ++i)
+        a[i * C + j] -= dot * a[i * C + k];
+    }
+    double n = 0;
+    for (size_t i = 0; i < R; ++i)
+      n += a[i * C + j] * a[i * C + j];
+    n = std::sqrt(n);
+    for (size_t i = 0; i < R; ++i)
+      a[i * C + j] /= n;
+  }
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t c = 0; c < cols; ++c)
+      w[r * cols + c] = (float)(gain * (tr ? a[c * C + r] : a[r * C + c]));
+}
+static std::vector<float> init_params(size_t H, size_t A, uint64_t seed) { // libtorch parameters() order
+  std::mt19937_64 g(seed);
+  const double s2 = std::sqrt(2.0);
+  struct T {
+    size_t rows, cols;
+    double gain;
+  };
+  const T t[6] = {{32, 4 * 8 * 8, s2}, {64, 32 * 4 * 4, s2}, {64, 64 * 3 * 3, s2}, {H, 3136, s2}, {A, H, 0.01}, {1, H, 1.0}};
+  std::vector<float> p;
+  for (const T &x : t) {
+    const size_t o = p.size();
+    p.resize(o + x.rows * x.cols + x.rows, 0.0f); // weight then zero bias
+    orthogonal(p.data() + o, x.rows, x.cols, x.gain, g);
+  }
+  return p;
+}
+
+static void check(aleppo_ctx *ctx, int rc) { // the reference throws at the same places
+  if (rc == ALEPPO_OK)
+    return;
+  const char *m = aleppo_last_error(ctx);
+  if (rc == ALEPPO_ERR_INVALID_ARGUMENT)
+    throw std::invalid_argument(m ? m : "invalid argument");
+  throw std::runtime_error(m ? m : "aleppo error");
+}
+template <class T> static float meanf(const std::vector<T> &v) {
+  return v.empty() ? 0.f : (float)(std::accumulate(v.begin(), v.end(), 0.0) / (double)v.size());
+}
+
+int main(int argc, char **argv) {
+  if (argc < 6) {
+    std::fprintf(stderr, "usage: %s <rom> <tensorboard log path> <video dir> <group> <config.yaml> [profile]\n", argv[0]);
+    return 2;
+  }
+  try {
+    const auto start_time = std::chrono::system_clock::now().time_since_epoch().count();
+    const std::string rom_path = argv[1], group = argv[4];
+    std::string log_path = argv[2];
+    { // replace_extension("tfevents.<start-time>") like train.cc:324-325
+      const size_t slash = log_path.find_last_of('/'), dot = log_path.find_last_of('.');
+      if (dot != std::string::npos && (slash == std::string::npos || dot > slash))
+        log_path = log_path.substr(0, dot);
+      log_path += ".tfevents." + std::to_string(start_time);
+    }
+    const Config cfg = load_config(argv[5]);
+    { // train.cc:347-352: create the log (and video) directories
+      const auto parent = std::filesystem::path(log_path).parent_path();
+      if (!parent.empty() && !std::filesystem::exists(parent))
+        std::filesystem::create_directories(parent);
+    }
+    const size_t E = cfg.total_environments, T = cfg.horizon, A = cfg.action_size;
+    if ((E * T) % (size_t)cfg.num_mini_batches)
+      throw std::runtime_error("Batch size must be divisible by num_mini_batches");
+    if (E % cfg.worker_batch_size)
+      std::cerr << "warning: total_environments % worker_batch_size != 0 would deadlock the reference's queue\n";
+    if (cfg.record_video)
+      std::cerr << "note: record_video ignored (no ffmpeg / ALE in this build)\n";
+
+    aleppo_config ac{};
+    ac.abi_version = ALEPPO_ABI_VERSION;
+    ac.device_ordinal = 0;
+    ac.world_size = 1;
+    ac.rank = 0;
+    ac.num_envs = (int32_t)E;
+    ac.horizon = (int32_t)T;
+    ac.num_actions = (int32_t)A;
+    ac.hidden_size = (int32_t)cfg.hidden_size;
+    ac.frame_stack = (int32_t)cfg.frame_stack;
+    ac.precision = cfg.precision == "bf16" ? ALEPPO_BF16 : ALEPPO_FP32;
+    ac.advantage_norm = cfg.advantage_norm;
+    ac.gamma = cfg.gae_discount;
+    ac.lambda = cfg.gae_lambda;
+    ac.clip_param = cfg.clip_param;
+    ac.value_loss_coef = cfg.value_loss_coef;
+    ac.entropy_coef = cfg.entropy_coef;
+    ac.max_gradient_norm = cfg.max_gradient_norm;
+    ac.seed = cfg.seed;
+    aleppo_ctx *ctx = nullptr;
+    check(nullptr, aleppo_create(&ac, &ctx));
+    std::cout << "MI355X is available! Training on GPU (rom argument '" << rom_path << "' -> synthetic emulator)."
+              << std::endl;
+    {
+      const std::vector<float> p = init_params(cfg.hidden_size, A, cfg.deterministic ? 42 : (uint64_t)start_time);
+      size_t n = 0;
+      check(ctx, aleppo_param_count(ctx, &n));
+      if (n != p.size())
+        throw std::runtime_error("parameter count mismatch");
+      check(ctx, aleppo_load_params(ctx, p.data(), p.size()));
+    }
+    EventWriter logger(log_path);
+
+    // ---- Rollout host half (src/ai/rollout.cc)
+    std::vector<SyntheticAtari> envs;
+    for (size_t i = 0; i < E; ++i)
+      envs.emplace_back(i + 0 /*seed arg of train.cc:380*/, cfg.max_steps, cfg.max_return, A);
+    std::vector<uint8_t> frames(E * 84 * 84), start_cpu(E, 1), term(E, 0), trunc(E, 0), game_over(E, 0);
+    std::vector<float> rewards(E, 0.f), ep_ret(E, 0.f), game_ret(E, 0.f);
+    std::vector<size_t> ep_len(E, 0), game_len(E, 0);
+    std::vector<StepOut> results(E);
+    const int64_t *actions = nullptr;
+    size_t total_steps = 0, episodes = 0;
+    std::cout << "Creating " << cfg.num_workers << " worker threads." << std::endl;
+    WorkerPool pool(cfg.num_workers, [&](size_t i) { // Rollout::step (rollout.cc:299-328)
+      if (start_cpu[i]) {
+        envs[i].reset(&frames[i * 7056]);
+        results[i] = StepOut{};
+      } else {
+        const int64_t a = actions[i];
+        if (a < 0 || (size_t)a >= A)
+          throw std::out_of_range("Action index out of range for environment " + std::to_string(i));
+        results[i] = envs[i].step((int)a, &frames[i * 7056]);
+      }
+    });
+    struct Log {
+      std::vector<float> episode_returns, game_returns;
+      std::vector<size_t> episode_lengths, game_lengths;
+    };
+    auto rollout = [&]() {
+      Log log;
+      for (size_t t = 0; t < T; ++t) {
+        check(ctx, aleppo_act(ctx, nullptr, &actions));
+        pool.run_all(E);
+        std::vector<uint8_t> start_at_entry = start_cpu;
+        for (size_t i = 0; i < E; ++i) {
+          if (!start_cpu[i]) { // rollout.cc:214-226 (start slots keep the stale reward)
+            rewards[i] = results[i].reward;
+            term[i] = results[i].terminated;
+            trunc[i] = results[i].truncated;
+            game_over[i] = results[i].game_over;
+            ep_ret[i] += results[i].reward;
+            ep_len[i]++;
+            game_ret[i] += results[i].reward;
+            game_len[i]++;
+            total_steps++;
+          }
+        }
+        check(ctx, aleppo_step(ctx, frames.data(), ALEPPO_FRAMES_84, ALEPPO_HOST, rewards.data(), term.data(),
+                               trunc.data(), start_at_entry.data()));
+        for (size_t i = 0; i < E; ++i) { // rollout.cc:239-265
+          if (results[i].terminated || results[i].truncated) {
+            start_cpu[i] = 1;
+            term[i] = trunc[i] = 0;
+            episodes++;
+            log.episode_returns.push_back(ep_ret[i]);
+            log.episode_lengths.push_back(ep_len[i]);
+            ep_ret[i] = 0;
+            ep_len[i] = 0;
+            if (game_over[i]) {
+              log.game_returns.push_back(game_ret[i]);
+              log.game_lengths.push_back(game_len[i]);
+              game_ret[i] = 0;
+              game_len[i] = 0;
+            }
+          } else if (start_cpu[i]) {
+            start_cpu[i] = 0;
+          }
+        }
+      }
+      check(ctx, aleppo_finish_rollout(ctx, nullptr));
+      return log;
+    };
+
+    rollout(); // the warm rollout before the loop (train.cc:391-396): collected, never trained on
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<aleppo_minibatch_metrics> m((size_t)cfg.num_epochs * (size_t)cfg.num_mini_batches);
+    for (size_t r = 0; r < cfg.num_rollouts; ++r) {
+      std::cout << "Rollout " << r + 1 << " of " << cfg.num_rollouts << std::endl;
+      const double lr = cfg.learning_rate * (1.0 - r / static_cast<double>(cfg.num_rollouts)); // train.cc:424-428
+      const Log log = rollout();
+      check(ctx, aleppo_train(ctx, lr, (int)cfg.num_epochs, (int)cfg.num_mini_batches, m.data()));
+      // log_data (train.cc:163-210): x axis = non-reset env steps
+      const int64_t step = (int64_t)total_steps;
+      if (!log.episode_returns.empty()) {
+        logger.add_scalar("mean_episode_return", step, meanf(log.episode_returns));
+        logger.add_scalar("mean_episode_length", step, meanf(log.episode_lengths));
+        logger.add_histogram("episode_returns", step, log.episode_returns);
+        if (!log.game_returns.empty()) {
+          logger.add_scalar("mean_game_return", step, meanf(log.game_returns));
+          logger.add_scalar("mean_game_length", step, meanf(log.game_lengths));
+        }
+      }
+      auto avg = [&](float aleppo_minibatch_metrics::*f) {
+        double s = 0;
+        for (auto &x : m)
+          s += x.*f;
+        return (float)(s / (double)m.size());
+      };
+      logger.add_scalar("mean_clipped_gradient", step, avg(&aleppo_minibatch_metrics::grad_norm));
+      logger.add_scalar("mean_loss", step, avg(&aleppo_minibatch_metrics::loss));
+      logger.add_scalar("mean_clipped_loss", step, avg(&aleppo_minibatch_metrics::clipped_loss));
+      logger.add_scalar("mean_value_loss", step, avg(&aleppo_minibatch_metrics::value_loss));
+      logger.add_scalar("mean_entropy", step, avg(&aleppo_minibatch_metrics::entropy));
+      logger.add_scalar("mean_ratio", step, avg(&aleppo_minibatch_metrics::ratio));
+      logger.add_scalar("learning_rate", step, (float)lr);
+      {
+        std::vector<float> gn;
+        for (auto &x : m)
+          gn.push_back(x.grad_norm);
+        if (gn.size() > 1)
+          logger.add_histogram("clipped_gradients", step, gn);
+      }
+      logger.flush();
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    std::cout << "steps " << total_steps << " episodes " << episodes << " env-steps/s "
+              << (double)(cfg.num_rollouts * E * T) / secs << std::endl;
+    aleppo_destroy(ctx);
+    std::cout << "Success" << std::endl;
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    return 1;
+  }
+}
