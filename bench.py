@@ -33,6 +33,17 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROA
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_bytes(dtype):
+    """algorithmic (minimum) HBM bytes per sample of each kernel: operands read once + result written once
+    (DESIGN.md section 4).  e = activation element size; obs is the packed uint8 stack; h is fp32."""
+    e = 2 if dtype == "bf16" else 4
+    obs, a1, a2, a3, h = 28224, 12800 * e, 5184 * e, 3136 * e, 512 * 4
+    dh = 512 * e
+    return dict(conv1_fwd=obs + a1, conv2_fwd=a1 + a2, conv3_fwd=a2 + a3, fc_fwd=a3 + h, fc_dgrad=dh + 2 * a3,
+                fc_wgrad=dh + a3, conv3_dgrad=a3 + 2 * a2, conv3_wgrad=a3 + a2, conv2_dgrad=a2 + 2 * a1,
+                conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs)
+
+
 def log(msg):
     sys.stderr.write(f"[bench {time.strftime('%H:%M:%S')}] {msg}\n")
     sys.stderr.flush()
@@ -177,16 +188,42 @@ def run(args):
         trn = {k: eng.profile_read(k) for k in pkg.KERNEL_CLASSES}
         eng.profile(False)
         B = E * T // M
-        gemm = {k: v[0] * v[1] for k, v in trn.items() if k in KFLOP}
-        dom = max(gemm, key=gemm.get)
-        peak = PEAK_TFLOPS[args.dtype]
-        achieved = KFLOP[dom] * B / (trn[dom][0] * 1e-3) / 1e12  # per launch: B samples
-        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(trn[dom][0], 4),
-                        launches=trn[dom][1], flop_per_launch=KFLOP[dom] * B)
+        KB = kernel_bytes(args.dtype)
+        peak_tf = PEAK_TFLOPS[args.dtype]
+        table = {}
+        for k in KFLOP:  # both rooflines per launch (B samples); the one with the LARGER minimum time bounds it
+            ms = trn[k][0]
+            if not ms:
+                continue
+            tf = KFLOP[k] * B / (ms * 1e-3) / 1e12
+            gbs = KB[k] * B / (ms * 1e-3) / 1e9
+            t_mfma, t_hbm = KFLOP[k] * B / (peak_tf * 1e12), KB[k] * B / (PEAK_HBM_GBS * 1e9)
+            table[k] = dict(ms=round(ms, 4), TFLOPs=round(tf, 1), GBps=round(gbs, 1),
+                            bound="hbm" if t_hbm >= t_mfma else "mfma",
+                            frac=round(max(t_hbm, t_mfma) / (ms * 1e-3), 4))
+        dom = max(table, key=lambda k: trn[k][0] * trn[k][1])
+        d = table[dom]
+        pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path) and args.dtype == "bf16" and B == 4096:
+            pmc = json.load(open(pmc_path)).get(dom)
+        if d["bound"] == "hbm":
+            roofline = dict(bound="hbm", kernel=dom, achieved=d["GBps"], peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(d["GBps"] / PEAK_HBM_GBS, 4),
+                            traffic=(pmc["traffic_MB"] * 1e6 if pmc else None),
+                            algorithmic_bytes_per_launch=KB[dom] * B)
+        else:
+            roofline = dict(bound="mfma", kernel=dom, achieved=d["TFLOPs"], peak=peak_tf, unit="TFLOP/s",
+                            frac=round(d["TFLOPs"] / peak_tf, 4), traffic=(pmc["traffic_MB"] * 1e6 if pmc else None),
+                            flop_per_launch=KFLOP[dom] * B)
+        roofline.update(avg_launch_ms=round(trn[dom][0], 4), launches=trn[dom][1],
+                        traffic_source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                       "FETCH x2 gfx950 correction)" if pmc else None)
         upd_ms = sum(v[0] * v[1] for v in trn.values())
         roofline["update_all_kernels_TFLOPs"] = round(sum(KFLOP.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e12, 2)
-        roofline["update_kernel_ms_per_minibatch"] = {k: round(v[0], 4) for k, v in trn.items() if v[1]}
+        roofline["update_all_kernels_GBps"] = round(sum(KB.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e9, 1)
+        roofline["update_kernels"] = table
+        roofline["update_other_kernel_ms"] = {k: round(v[0], 4) for k, v in trn.items() if v[1] and k not in KFLOP}
         roofline["acting_kernel_ms_per_step"] = {k: round(v[0], 4) for k, v in act.items() if v[1]}
         ing_ms = act["ingest"][0]
         roofline["hbm_kernels"] = dict(
@@ -230,13 +267,13 @@ def cpu_baseline():
     log(f"cpu baseline: reference harness on {threads} threads")
     if os.path.exists(exe):
         try:
-            out = subprocess.run([exe, "bench", "8", "128", "512", "4", "4", "4", "6", str(threads)], check=True,
+            out = subprocess.run([exe, "bench", "8", "128", "512", "4", "4", "4", "24", str(threads)], check=True,
                                  capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1]
             j = json.loads(out)
             return {"value": round(j["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": threads,
                     "kind": "reference",
                     "sample": "configs/v0.yaml shape: 8 envs x T=128, 4 epochs x 4 minibatches of 256, H=512, "
-                              f"6 rollouts+updates after 1 warm-up ({j['seconds']:.1f} s), libtorch CPU"}
+                              f"24 rollouts+updates after 1 warm-up ({j['seconds']:.1f} s), libtorch CPU"}
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f"reference cpu baseline failed ({e}); falling back to the C port\n")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -256,8 +293,8 @@ def cpu_baseline():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=128, help="environments per GPU (configs[1]: 128)")
     ap.add_argument("--horizon", type=int, default=128)
     ap.add_argument("--actions", type=int, default=4)
