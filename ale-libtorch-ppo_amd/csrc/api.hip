@@ -644,7 +644,7 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   prof_end(c, ALEPPO_K_GAE);
   if (c->cfg.advantage_norm) {
     launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 0);
-    if (c->world > 1 && c->nccl_comm)
+    if ((c->world > 1 || c->force_comm) && c->nccl_comm)
       NCCLCHK(c, ncclAllReduce(c->adv_stats, c->adv_stats, 3, ncclFloat, ncclSum,
                                static_cast<ncclComm_t>(c->nccl_comm), c->stream));
     launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 1);
@@ -707,7 +707,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   if (rc)
     return rc;
   ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_comm);
-  const bool dp = c->world > 1;
+  const bool dp = c->world > 1 || (c->nccl_comm && c->force_comm); // force_comm: 1-rank communicator (tests)
   const int H = c->H, A = c->A, prec = c->prec;
   const ParamLayout &L = c->L;
   hipStream_t s = c->stream;
@@ -1010,6 +1010,8 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     set_patch_kernels(value == 0);
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
+  else if (option == ALEPPO_OPT_FORCE_COMM)
+    c->force_comm = value != 0;
   else
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
   return ALEPPO_OK;

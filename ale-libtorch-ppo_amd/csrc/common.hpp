@@ -126,6 +126,7 @@ struct Ctx {
   // ---- profiling ----
   bool prof_on = false;
   bool dbg_no_publish = false;
+  bool force_comm = false;
   ProfClass prof[ALEPPO_K_COUNT];
 };
 

@@ -5,6 +5,7 @@
 // conversions used only at the C-ABI boundary.  Each kernel cites the reference code it replaces.
 #include "common.hpp"
 #include "gemm.hpp" // bf16 / vector typedefs
+#include <cstdlib>
 
 namespace aleppo {
 
@@ -409,22 +410,45 @@ void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long
 // 1/N_m uses the GLOBAL unmasked count so that an all-reduce SUM over ranks yields the mean (8e).
 // ================================================================================================
 template <class T, int AMAX>
-__global__ __launch_bounds__(256) void head_train_kernel(
+__global__ __launch_bounds__(512) void head_train_kernel(
     const float *__restrict__ h, const float *__restrict__ Wh, const float *__restrict__ bh,
     const int *__restrict__ act, const float *__restrict__ oldlp, const float *__restrict__ adv,
     const float *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
     T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
-    float *slab_b, long B, int H, int A, float *logits_out, float *values_out) {
+    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int abl) {
   constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
+  constexpr int NWV = 8;                // waves per workgroup
   extern __shared__ float smem[];
   float *sW = smem;                    // [(A+1)][H]
   float *sAcc = smem + (size_t)A1 * H; // [(A+1)][H] cross-wave wgrad accumulator
-  float *sB = sAcc + (size_t)A1 * H;   // [4][A1]
+  float *sB = sAcc + (size_t)(A1 > NWV ? A1 : NWV) * H; // [NWV][A1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < (A + 1) * H; i += 256) {
+  const long rows_per_blk = (B + gridDim.x - 1) / gridDim.x;
+  const long row0 = (long)blockIdx.x * rows_per_blk, row1 = min(B, row0 + rows_per_blk);
+  // Everything a row needs (h, action, advantage, return, mask and ALL A old log-probs, so that nothing is a
+  // dependent load) is fetched ONE ROW AHEAD: a row's memory round trips hide behind the previous row's math.
+  // The first row's loads are issued before the weight staging below.
+  float hnext[HPL], olp_n[AMAX], adv_n = 0.f, ret_n = 0.f;
+  int act_n = 0;
+  bool mask_n = false;
+  auto fetch = [&](long r) {
+    const bool ok = r < row1;
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) {
+      const int j = lane + 64 * i;
+      hnext[i] = (ok && j < H) ? h[(size_t)r * H + j] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      olp_n[a] = (ok && a < A) ? oldlp[(size_t)r * A + a] : 0.f;
+    act_n = ok ? act[r] : 0;
+    adv_n = ok ? adv[r] : 0.f;
+    ret_n = ok ? ret[r] : 0.f;
+    mask_n = ok ? mask[r] != 0 : false;
+  };
+  fetch(row0 + wave);
+  for (int i = tid; i < (A + 1) * H; i += 64 * NWV)
     sW[i] = Wh[i];
-    sAcc[i] = 0.f;
-  }
   __syncthreads();
   const float inv_nm = 1.0f / mask_count[0];
   float gW[A1][HPL], gb[A1];
@@ -435,15 +459,18 @@ __global__ __launch_bounds__(256) void head_train_kernel(
     for (int i = 0; i < HPL; ++i)
       gW[a][i] = 0.f;
   }
-  const long rows_per_blk = (B + gridDim.x - 1) / gridDim.x;
-  const long row0 = (long)blockIdx.x * rows_per_blk, row1 = min(B, row0 + rows_per_blk);
-  for (long row = row0 + wave; row < row1; row += 4) {
-    float hv[HPL];
+  for (long row = row0 + wave; row < row1; row += NWV) {
+    float hv[HPL], olp_c[AMAX];
 #pragma unroll
-    for (int i = 0; i < HPL; ++i) {
-      const int j = lane + 64 * i;
-      hv[i] = j < H ? h[(size_t)row * H + j] : 0.f;
-    }
+    for (int i = 0; i < HPL; ++i)
+      hv[i] = hnext[i];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a)
+      olp_c[a] = olp_n[a];
+    const int ai = act_n;
+    const float advi = adv_n, reti = ret_n;
+    const bool maski = mask_n;
+    fetch(row + NWV); // next row of this wave
     float z[A1];
 #pragma unroll
     for (int a = 0; a < A1; ++a) {
@@ -479,7 +506,6 @@ __global__ __launch_bounds__(256) void head_train_kernel(
       if (a < A)
         se += expf(z[a] - mx);
     const float lse = mx + logf(se);
-    const int ai = act[row];
     float lp[AMAX], p[AMAX], ent = 0.f, lpa = 0.f, olpa = 0.f;
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
@@ -491,12 +517,11 @@ __global__ __launch_bounds__(256) void head_train_kernel(
         ent += p[a] * lp[a];           // losses.cc:41-43
         if (a == ai) {
           lpa = lp[a];
-          olpa = oldlp[(size_t)row * A + a];
+          olpa = olp_c[a];
         }
       }
     }
     ent = -ent;
-    const float advi = adv[row], reti = ret[row];
     const float rho = expf(lpa - olpa);                                  // losses.cc:33
     const float crho = fminf(fmaxf(rho, 1.0f - hp.clip), 1.0f + hp.clip); // losses.cc:34-35
     const float un = rho * advi, cl = crho * advi;
@@ -504,7 +529,7 @@ __global__ __launch_bounds__(256) void head_train_kernel(
     const float dv = value - reti;
     const float lv = 0.5f * (dv * dv);                                   // losses.cc:15
     const float Ltot = -obj + hp.c_v * lv - hp.c_e * ent;                // losses.cc:17-18
-    const float m = mask[row] ? inv_nm : 0.f;                            // losses.cc:19 masked mean
+    const float m = maski ? inv_nm : 0.f;                                // losses.cc:19 masked mean
     const bool active = advi >= 0.f ? (rho <= 1.0f + hp.clip) : (rho >= 1.0f - hp.clip);
     const float gs = active ? -rho * advi : 0.f;
     float dz[A1];
@@ -550,31 +575,51 @@ __global__ __launch_bounds__(256) void head_train_kernel(
     for (int a = 0; a < A1; ++a)
       gb[a] += dz[a];
   }
-  // ordered cross-wave accumulation (deterministic)
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int a = 0; a < A1; ++a)
-        if (a <= A) {
-#pragma unroll
-          for (int i = 0; i < HPL; ++i) {
-            const int j = lane + 64 * i;
-            if (j < H)
-              sAcc[a * H + j] += gW[a][i];
-          }
-          if (lane == 0)
-            sB[w * A1 + a] = gb[a];
-        }
-    }
-    __syncthreads();
-  }
+  // deterministic cross-wave reduction, one head row at a time: every wave writes its partial of row a, then
+  // thread j adds the NWV partials of column j in fixed order and stores the workgroup's slab entry
+  (void)abl;
+  float *sPart = sAcc; // [NWV][H] (reuses the accumulator region: (A+1)*H >= ... is not needed, H*NWV floats)
   float *ow = slab_w + (size_t)blockIdx.x * (A + 1) * H;
-  for (int i = tid; i < (A + 1) * H; i += 256)
-    ow[i] = sAcc[i];
-  if (tid <= A)
-    slab_b[(size_t)blockIdx.x * (A + 1) + tid] = (sB[tid] + sB[A1 + tid]) + (sB[2 * A1 + tid] + sB[3 * A1 + tid]);
+#pragma unroll
+  for (int a = 0; a < A1; ++a) {
+    if (a <= A) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < HPL; ++i) {
+        const int j = lane + 64 * i;
+        if (j < H)
+          sPart[wave * H + j] = gW[a][i];
+      }
+      if (lane == 0)
+        sB[wave * A1 + a] = gb[a];
+      __syncthreads();
+      for (int j = tid; j < H; j += 64 * NWV) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w)
+          sum += sPart[w * H + j];
+        ow[a * H + j] = sum;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid <= A) {
+    float sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w)
+      sb += sB[w * A1 + tid];
+    slab_b[(size_t)blockIdx.x * (A + 1) + tid] = sb;
+  }
 }
 
+static int head_abl() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = std::getenv("ALEPPO_HEAD_ABL");
+    v = e ? std::atoi(e) : 0;
+  }
+  return v;
+}
 template <class T>
 static void head_train_t(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
                          const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
@@ -583,13 +628,13 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
                          long B, int H, int A, float *lo, float *vo) {
 #define LAUNCH_HEAD(AM)                                                                                                \
   do {                                                                                                                 \
-    const size_t sm = ((size_t)2 * (AM + 1) * H + 4 * (AM + 1)) * sizeof(float);                                       \
+    const size_t sm = ((size_t)((AM + 1) + ((AM + 1) > 8 ? (AM + 1) : 8)) * H + 8 * (AM + 1)) * sizeof(float);        \
     if (sm > 48 * 1024)                                                                                                \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&head_train_kernel<T, AM>),                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
-    hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(256), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
+    hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(512), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
                        mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
-                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo);                                                     \
+                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, head_abl());                                         \
   } while (0)
   if (A <= 4)
     LAUNCH_HEAD(4);

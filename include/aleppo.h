@@ -244,7 +244,8 @@ int aleppo_profile_reset(aleppo_ctx *ctx);
  * gather-GEMM kernels instead of the sample-stationary ones (same math, used by the parity tests). */
 typedef enum {
   ALEPPO_OPT_GENERIC_CONV = 0,
-  ALEPPO_OPT_DEBUG_NO_PUBLISH = 1 /* diagnosis only: the head kernel skips the pinned-memory hand-off */
+  ALEPPO_OPT_DEBUG_NO_PUBLISH = 1, /* diagnosis only: the head kernel skips the pinned-memory hand-off */
+  ALEPPO_OPT_FORCE_COMM = 2        /* tests: run the RCCL all-reduce path even with a 1-rank communicator */
 } aleppo_option;
 int aleppo_set_option(aleppo_ctx *ctx, int option, int value);
 /* Block until everything enqueued on ctx's streams has finished. */

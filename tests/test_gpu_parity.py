@@ -395,6 +395,34 @@ def test_bf16_acting_path_close_to_oracle(pkg):
     eng.close()
 
 
+@pytest.mark.parametrize("prec", ["bf16"])  # one precision: the 1-rank communicator init alone takes ~60 s
+def test_rccl_path_with_one_rank_communicator(pkg, prec):
+    """the data-parallel code path of aleppo_train (mask-count / bucketed gradient / metric all-reduces on the
+    side stream, event choreography) executed with a 1-rank RCCL communicator: identical results to the
+    no-communicator path (N>1 GPUs are only available to the round-end driver)"""
+    H, A, N, M = 64, 4, 64, 2
+    params = hf.fill_params(910, H, A)
+    obs = hf.hf_bytes(911, (N, 4, 84, 84))
+    actions = (hf.hf_u32(912, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(913, (N, A), -1, 1))
+    adv, ret = hf.hf_range(914, (N,), -1, 1), hf.hf_range(915, (N,), -1, 1)
+    masks = (hf.hf_unit(916, N) >= np.float32(0.2)).astype(np.uint8)
+    out = []
+    for comm in (False, True):
+        eng = pkg.Engine(8, 8, A, H, precision=pkg.FP32 if prec == "fp32" else pkg.BF16, advantage_norm=False)
+        if comm:
+            eng.comm_init(pkg.Engine.comm_unique_id())
+            eng._c(pkg.lib().aleppo_set_option(eng._ctx, 2, 1))
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 2, M)
+        out.append((m, eng.export_params()))
+        eng.close()
+    np.testing.assert_array_equal(out[0][0]["loss"], out[1][0]["loss"])
+    np.testing.assert_array_equal(out[0][0]["grad_norm"], out[1][0]["grad_norm"])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 def test_buffer_not_full_and_bad_minibatch_errors(pkg):
     eng = pkg.Engine(4, 4, 4, 32)
     with pytest.raises(pkg.AleppoError, match="Buffer is not full"):
