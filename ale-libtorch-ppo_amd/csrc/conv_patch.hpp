@@ -282,46 +282,47 @@ struct ActConvParams {
   long ns;
 };
 
-// one forward phase out of LDS patch `pb`; writes 4 channels x 1 pixel per lane through `store(q, oc, v4)`
-template <class L, class Store>
-__device__ __forceinline__ void act_phase(const bf16 *pb, const bf16 *w, const float *bias, float scale, int wave,
-                                          int lane, Store store) {
-  constexpr int K = 32 * L::KS, NL = 8 / L::OG, NATOM = (L::PIX + 15) / 16, SEG = L::KW * L::C;
-  const int og = wave % L::OG, pl = wave / L::OG, fr = lane & 15, fg = lane >> 4;
-  u32x4 W[2][L::KS];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
+// Acting phases use ONE 16-channel atom per wave (8 waves = MA channel atoms x 8/MA pixel lanes): the weights
+// of all three layers then fit in registers together (8 + 16 + 18 fragments = 168 VGPRs) and are loaded once,
+// at kernel start, overlapped with staging the observation - no exposed weight round trip between phases.
+template <class L> struct ActW {
+  static constexpr int MA = L::OUTC / 16, NL = 8 / MA;
+  u32x4 w[L::KS];
+  float br[4];
+  __device__ __forceinline__ void load(const bf16 *wp, const float *bias, int wave, int lane) {
+    const int og = wave % MA, fr = lane & 15, fg = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < L::KS; ++ks)
-      W[a][ks] = *reinterpret_cast<const u32x4 *>(w + (long)(og * 32 + a * 16 + fr) * K + ks * 32 + fg * 8);
-  const int oc0 = og * 32 + fg * 4;
-  float br[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
+      w[ks] = *reinterpret_cast<const u32x4 *>(wp + (long)(og * 16 + fr) * (32 * L::KS) + ks * 32 + fg * 8);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      br[a][r] = bias[oc0 + a * 16 + r];
+      br[r] = bias[og * 16 + fg * 4 + r];
+  }
+};
+// one forward phase out of LDS patch `pb`; writes 4 channels x 1 pixel per lane through `store(q, oc, v4)`
+template <class L, class Store>
+__device__ __forceinline__ void act_phase(const bf16 *pb, const ActW<L> &W, float scale, int wave, int lane,
+                                          Store store) {
+  constexpr int MA = ActW<L>::MA, NL = ActW<L>::NL, NATOM = (L::PIX + 15) / 16, SEG = L::KW * L::C;
+  const int og = wave % MA, pl = wave / MA, fr = lane & 15, fg = lane >> 4;
+  const int oc0 = og * 16 + fg * 4;
   for (int atom = pl; atom < NATOM; atom += NL) {
     const int q = atom * 16 + fr;
     const bool qok = q < L::PIX;
     const int oy = q / L::OW, ox = q - oy * L::OW;
     const int base = qok ? ((oy * L::S) * L::IW + ox * L::S) * L::CP + fg * 8 : fg * 8;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < L::KS; ++ks) {
       const int rem = (ks * 32) % SEG;
       const int koff = L::C >= 32 ? (((ks * 32) / SEG) * L::IW + rem / L::C) * L::CP + rem % L::C
                                   : ((ks * 32) / SEG) * (L::IW * L::CP) + rem;
       const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
-      Atom<bf16>::mma(W[0][ks], b, acc0);
-      Atom<bf16>::mma(W[1][ks], b, acc1);
+      Atom<bf16>::mma(W.w[ks], b, acc);
     }
-    if (qok) {
-      store(q, oc0, pack4_bf16(fmaxf(acc0[0] * scale + br[0][0], 0.f), fmaxf(acc0[1] * scale + br[0][1], 0.f),
-                               fmaxf(acc0[2] * scale + br[0][2], 0.f), fmaxf(acc0[3] * scale + br[0][3], 0.f)));
-      store(q, oc0 + 16, pack4_bf16(fmaxf(acc1[0] * scale + br[1][0], 0.f), fmaxf(acc1[1] * scale + br[1][1], 0.f),
-                                    fmaxf(acc1[2] * scale + br[1][2], 0.f), fmaxf(acc1[3] * scale + br[1][3], 0.f)));
-    }
+    if (qok)
+      store(q, oc0, pack4_bf16(fmaxf(acc[0] * scale + W.br[0], 0.f), fmaxf(acc[1] * scale + W.br[1], 0.f),
+                               fmaxf(acc[2] * scale + W.br[2], 0.f), fmaxf(acc[3] * scale + W.br[3], 0.f)));
   }
 }
 
@@ -332,6 +333,10 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16 *sx = reinterpret_cast<bf16 *>(smem), *s1 = sx + ACT_X_ELEMS, *s2 = s1 + ACT_A1_ELEMS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ActW<LConv1Full> W1;
+  ActW<LConv2FwdSmall> W2;
+  ActW<LConv3FwdSmall> W3;
+  bool have_w = false;
   for (long n = blockIdx.x; n < P.ns; n += gridDim.x) {
     { // stage + widen the packed u8 stack: 1764 16-byte vectors
       const long nn = n + P.map.n0;
@@ -345,6 +350,12 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
       for (int i = 0; i < 4; ++i) {
         const int v = tid + 512 * i;
         R[i] = v < 1764 ? src[v] : zero16();
+      }
+      if (!have_w) { // all three layers' weights: issued behind the observation loads, consumed much later
+        W1.load(P.w1, P.b1, wave, lane);
+        W2.load(P.w2, P.b2, wave, lane);
+        W3.load(P.w3, P.b3, wave, lane);
+        have_w = true;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -361,14 +372,14 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
       }
     }
     __syncthreads();
-    act_phase<LConv1Full>(sx, P.w1, P.b1, 1.0f / 255.0f, wave, lane,
+    act_phase<LConv1Full>(sx, W1, 1.0f / 255.0f, wave, lane,
                           [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s1 + q * LConv2Fwd::CP + oc) = v; });
     __syncthreads();
-    act_phase<LConv2FwdSmall>(s1, P.w2, P.b2, 1.0f, wave, lane,
+    act_phase<LConv2FwdSmall>(s1, W2, 1.0f, wave, lane,
                               [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s2 + q * LConv3Fwd::CP + oc) = v; });
     __syncthreads();
     bf16 *out = P.a3 + n * (long)(49 * 64);
-    act_phase<LConv3FwdSmall>(s2, P.w3, P.b3, 1.0f, wave, lane,
+    act_phase<LConv3FwdSmall>(s2, W3, 1.0f, wave, lane,
                               [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(out + q * 64 + oc) = v; });
     __syncthreads();
   }
