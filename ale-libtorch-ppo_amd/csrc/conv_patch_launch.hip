@@ -72,7 +72,7 @@ void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float 
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),
                 ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
-  launch_patch<LConv3DgradW4, 4, 2>(s, P);
+  launch_patch<LConv3Dgrad, 8, 1>(s, P); // the 4-wave / 2-per-CU variant measured slower here (56 vs 48 us)
 }
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
   PatchParams P{dz2, static_cast<const bf16 *>(W2d), nullptr, static_cast<const bf16 *>(a1), static_cast<bf16 *>(dz1),

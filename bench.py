@@ -233,6 +233,15 @@ def run(args):
             head_GBps=round((97 + 2 * 512 * 4) * B / (trn["head"][0] * 1e-3) / 1e9, 1))
         roofline["phase_wall_ms"] = {k: round(v, 3) for k, v in phase.items()}
 
+    # ---- secondary leg: the reference's configs/v1.yaml shape (4096 envs x T=5, 1 epoch, 16 minibatches of 1280) -
+    # the configuration its published ~26 k env-steps/s was quoted on.  N=1 only, reported beside `value`.
+    v1 = None
+    if rank == 0 and world == 1 and not args.no_v1:
+        try:
+            v1 = v1_shape_leg(pkg, args, local_rank)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"v1-shape leg failed: {e}\n")
+
     # ---- CPU baseline beside it (rank 0, N=1 only): the reference's own compiled CPU-libtorch path
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -249,13 +258,57 @@ def run(args):
                        "envs_per_gpu": E, "horizon": T, "epochs": epochs, "minibatches": M,
                        "parallelism": f"dp{world}", "frames": "raw u8 [E,2,210,160] pairs resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu,
-            "vs_reference_published_v1_26289": round(value / 26289.0, 2),
+            "vs_reference_published_v1_26289": round(value / 26289.0, 2), "v1_shape": v1,
             "last_loss": float(metrics["loss"][-1, -1]), "last_grad_norm": float(metrics["grad_norm"][-1, -1]),
         }
         print(json.dumps(out))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def v1_shape_leg(pkg, args, device):
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashfill as hf
+    E, T, A, H, epochs, M = 4096, 5, 4, 512, 1, 16
+    prec = pkg.BF16 if args.dtype == "bf16" else pkg.FP32
+    eng = pkg.Engine(E, T, A, H, precision=prec, device=device, clip_param=0.2, value_loss_coef=0.4, seed=7,
+                     max_minibatch=E * T // M)
+    eng.load_params(hf.fill_params(310, H, A))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    frames = torch.randint(0, 256, (T, E, 84, 84), device="cuda", generator=g, dtype=torch.int16).to(torch.uint8)
+    base, slot = frames.data_ptr(), E * 84 * 84
+    rng = np.random.default_rng(7)
+    rew = np.where(rng.random((T, E)) < 0.05, 1.0, 0.0).astype(np.float32)
+    z = np.zeros((T, E), np.uint8)
+    st0 = np.ones((T, E), np.uint8)
+    st0[1:] = 0
+    steps = 12
+
+    def one(first):
+        st = st0 if first else z
+        ra, za, sa = rew.ctypes.data, z.ctypes.data, st.ctypes.data
+        for t in range(T):
+            eng.act_fast()
+            eng.step_ptr(base + t * slot, pkg.DEVICE, pkg.FRAMES_84, ra + 4 * E * t, za + E * t, za + E * t, sa + E * t)
+        eng.finish_rollout()
+        eng.train(2.5e-4, epochs, M)
+
+    one(True)
+    for _ in range(3):
+        one(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.close()
+    return {"value": round(E * T * steps / dt, 1), "unit": "env-steps/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "workload": "4096 envs x T=5, 1 epoch x 16 minibatches of 1280, pre-resized 84x84 frames in HBM",
+            "vs_reference_published_v1_26289": round(E * T * steps / dt / 26289.0, 2)}
 
 
 def cpu_baseline():
@@ -302,4 +355,5 @@ if __name__ == "__main__":
     ap.add_argument("--minibatches", type=int, default=4)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-v1", action="store_true", help="skip the secondary v1.yaml-shape leg")
     run(ap.parse_args())

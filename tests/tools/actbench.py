@@ -1,8 +1,9 @@
 """acting micro-bench helper (not a test)"""
 import os, sys, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/
+sys.path.insert(0, _T)
+sys.path.insert(0, os.path.dirname(_T))
 import hashfill as hf
 from __graft_entry__ import load_package
 pkg = load_package()

@@ -1,8 +1,9 @@
 """debug helper (not a test)"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_T = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/
+sys.path.insert(0, _T)
+sys.path.insert(0, os.path.dirname(_T))
 import hashfill as hf
 import oracle_lib as orc
 from __graft_entry__ import load_package
