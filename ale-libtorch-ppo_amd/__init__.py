@@ -47,7 +47,8 @@ EXPORTS = [
     "aleppo_read_train_metric", "aleppo_set_batch", "aleppo_read_batch", "aleppo_forward", "aleppo_comm_unique_id",
     "aleppo_comm_init", "aleppo_gae", "aleppo_vision_resize_area", "aleppo_vision_rgb_to_gray", "aleppo_preprocess",
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
-    "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option",
+    "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option", "aleppo_export_optimizer",
+    "aleppo_import_optimizer",
 ]
 
 
@@ -274,6 +275,20 @@ class Engine:
         out = np.zeros(self.param_count, np.float32)
         self._c(lib().aleppo_export_grads(self._ctx, _ptr(out), C.c_size_t(out.size)))
         return out
+
+    # -- checkpoint / resume --
+    def state_dict(self):
+        m = np.zeros(self.param_count, np.float32)
+        v = np.zeros(self.param_count, np.float32)
+        step = C.c_int64()
+        self._c(lib().aleppo_export_optimizer(self._ctx, _ptr(m), _ptr(v), C.byref(step), C.c_size_t(m.size)))
+        return dict(params=self.export_params(), exp_avg=m, exp_avg_sq=v, step=np.int64(step.value))
+
+    def load_state_dict(self, sd):
+        self.load_params(sd["params"])  # resets Adam, then restore it
+        m, v = _f32(sd["exp_avg"]).ravel(), _f32(sd["exp_avg_sq"]).ravel()
+        self._c(lib().aleppo_import_optimizer(self._ctx, _ptr(m), _ptr(v), C.c_int64(int(sd["step"])),
+                                              C.c_size_t(m.size)))
 
     # -- rollout --
     def act(self, noise=None):

@@ -432,6 +432,35 @@ extern "C" int aleppo_export_grads(aleppo_ctx *c, float *flat, size_t count) {
   return export_flat(c, c->Gs, flat, count);
 }
 
+extern "C" int aleppo_export_optimizer(aleppo_ctx *c, float *exp_avg, float *exp_avg_sq, int64_t *step,
+                                       size_t count) {
+  CHECK_CTX(c);
+  if (!step)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null step");
+  int rc = export_flat(c, c->M1, exp_avg, count);
+  if (rc)
+    return rc;
+  rc = export_flat(c, c->M2, exp_avg_sq, count);
+  if (rc)
+    return rc;
+  *step = c->adam_step;
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_import_optimizer(aleppo_ctx *c, const float *exp_avg, const float *exp_avg_sq, int64_t step,
+                                       size_t count) {
+  CHECK_CTX(c);
+  if (!exp_avg || !exp_avg_sq || count != c->L.reference_count() || step < 0)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "import_optimizer: bad argument");
+  std::vector<float> tmp(c->L.total());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  params_to_internal(c->L, exp_avg, tmp.data());
+  HIPCHK(c, hipMemcpy(c->M1, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  params_to_internal(c->L, exp_avg_sq, tmp.data());
+  HIPCHK(c, hipMemcpy(c->M2, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  c->adam_step = step;
+  return ALEPPO_OK;
+}
+
 // ------------------------------------------------------------------ rollout
 static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst, float *values_dst, int *actions_dst,
                   bool publish) {

@@ -125,6 +125,12 @@ int aleppo_export_params(aleppo_ctx *ctx, float *flat, size_t count);
 /* Gradient of the LAST minibatch as clip_grad_norm_ left it (scaled), same order. Parity dumps. */
 int aleppo_export_grads(aleppo_ctx *ctx, float *flat, size_t count);
 
+/* Checkpoint / resume (the reference has none): Adam moments in the same order as the
+ * parameters plus the step count; together with aleppo_export_params this is the whole learner state. */
+int aleppo_export_optimizer(aleppo_ctx *ctx, float *exp_avg, float *exp_avg_sq, int64_t *step, size_t count);
+int aleppo_import_optimizer(aleppo_ctx *ctx, const float *exp_avg, const float *exp_avg_sq, int64_t step,
+                            size_t count);
+
 /* ------------------------------------------------------------------ rollout (Rollout::rollout, rollout.cc:198-278)
  * Per slot t = 0..T-1 the caller does  act -> (step its emulators) -> push_frames -> record_step,
  * then finish_rollout.  aleppo_step = push_frames + record_step in one upload. */

@@ -423,6 +423,29 @@ def test_rccl_path_with_one_rank_communicator(pkg, prec):
     np.testing.assert_array_equal(out[0][1], out[1][1])
 
 
+def test_checkpoint_resume_is_bit_identical(pkg):
+    H, A, N, M = 64, 4, 64, 2
+    params = hf.fill_params(930, H, A)
+    obs = hf.hf_bytes(931, (N, 4, 84, 84))
+    batch = (obs, (hf.hf_u32(932, N) % np.uint32(A)).astype(np.int64), orc.log_softmax(hf.hf_range(933, (N, A), -1, 1)),
+             hf.hf_range(934, (N,), -1, 1), hf.hf_range(935, (N,), -1, 1), np.ones(N, np.uint8))
+    a = pkg.Engine(8, 8, A, H)
+    a.load_params(params)
+    a.set_batch(*batch)
+    a.train(2.5e-4, 1, M)
+    sd = a.state_dict()
+    assert int(sd["step"]) == M and np.abs(sd["exp_avg_sq"]).sum() > 0
+    a.train(2.0e-4, 1, M)
+    want = a.export_params()
+    a.close()
+    b = pkg.Engine(8, 8, A, H)
+    b.load_state_dict(sd)
+    b.set_batch(*batch)
+    b.train(2.0e-4, 1, M)
+    np.testing.assert_array_equal(b.export_params(), want)
+    b.close()
+
+
 def test_buffer_not_full_and_bad_minibatch_errors(pkg):
     eng = pkg.Engine(4, 4, 4, 32)
     with pytest.raises(pkg.AleppoError, match="Buffer is not full"):
