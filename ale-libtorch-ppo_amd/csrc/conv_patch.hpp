@@ -34,19 +34,19 @@ struct LConv1Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
-                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4;
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0;
 };
 struct LConv2Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OUTC = 64, KS = 16,
-                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40;
+                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0;
 };
 struct LConv3Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
-                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 72;
+                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32;
 };
 // acting-size variants (ns <= 256): one sample per group so that every CU gets a workgroup
 struct LConv2FwdSmall : LConv2Fwd {
@@ -60,13 +60,30 @@ struct LConv3Dgrad {
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
-                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72;
+                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72, RPAD = 80, SPAD = 0;
 };
 struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
-                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 72;
+                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 80, RPAD = 80, SPAD = 0;
+};
+
+// LDS image of one unit: pixel (row, col) of the source at row*RP + col*CP bf16 elements, units SP apart.  The pixel
+// pitch CP, the row padding RPAD and the unit padding SPAD are chosen (tests/tools/lds_conflicts.py simulates the
+// gfx950 ds_read_b128 lane groups) so that the 16 lanes of a group hit 16 different 16-byte slots for almost every
+// (atom, k-step): 4.1-5.3 LDS cycles per fragment read instead of 7.4-11.2 with a plain padded pixel pitch.
+template <class L> constexpr int patch_src_width() { // source row width in pixels
+  if constexpr (L::MODE == PM_FWD)
+    return L::IW;
+  else
+    return L::OW;
+}
+template <class L> struct PatchGeom {
+  static constexpr int IWL = patch_src_width<L>();
+  static constexpr int ROWS = L::IN_ELEMS / L::C / IWL;
+  static constexpr int RP = IWL * L::CP + L::RPAD;
+  static constexpr int SP = ROWS * RP + L::SPAD;
 };
 
 struct PatchParams {
@@ -92,7 +109,8 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
   constexpr bool U8 = sizeof(InT) == 1;
   constexpr int K = 32 * L::KS;
   constexpr int PATCH = L::IN_ELEMS;                         // source elements per unit
-  constexpr int LPATCH = PATCH / L::C * L::CP;               // bf16 elements per unit in LDS (padded pixel pitch)
+  using GEO = PatchGeom<L>;
+  constexpr int LPATCH = GEO::SP, RP = GEO::RP;              // bf16 elements per unit / per source row in LDS
   constexpr int BUF_ELEMS = (L::SB * LPATCH + 63) / 64 * 64; // per buffer
   constexpr int SRC_VECS = L::SB * PATCH * (int)sizeof(InT) / 16; // 16-byte source vectors per group
   constexpr int NT = 64 * NW;                                // threads per workgroup
@@ -171,9 +189,10 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
           }
           reinterpret_cast<u32x4 *>(dst)[2 * v] = o0;
           reinterpret_cast<u32x4 *>(dst)[2 * v + 1] = o1;
-        } else { // vector v = 8 channels of pixel v / (C/8): padded pixel pitch CP
-          constexpr int VPP = L::C / 8;
-          *reinterpret_cast<u32x4 *>(dst + (v / VPP) * L::CP + (v % VPP) * 8) = R[i];
+        } else { // vector v = 8 channels of pixel (v / VPP) % PIXIN of unit v / (VPP * PIXIN)
+          constexpr int VPP = L::C / 8, PIXIN = PATCH / L::C;
+          const int px = v / VPP, u = px / PIXIN, pp = px - u * PIXIN, row = pp / GEO::IWL, col = pp - row * GEO::IWL;
+          *reinterpret_cast<u32x4 *>(dst + u * LPATCH + row * RP + col * L::CP + (v % VPP) * 8) = R[i];
         }
       }
     }
@@ -196,14 +215,14 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
       long out_off;
       if constexpr (L::MODE == PM_FWD) {
         const int oy = p / L::OW, ox = p - oy * L::OW;
-        const int base = qok ? s * LPATCH + ((oy * L::S) * L::IW + ox * L::S) * L::CP + fg * 8 : fg * 8;
+        const int base = qok ? s * LPATCH + (oy * L::S) * RP + (ox * L::S) * L::CP + fg * 8 : fg * 8;
         constexpr int SEG = L::KW * L::C;
 #pragma unroll
         for (int ks = 0; ks < L::KS; ++ks) {
           // k = 32ks + 8fg + j  ->  (kh, kw, c):  kh = 32ks / SEG, kw*C + c = 32ks % SEG (+ 8fg + j)
           const int rem = (ks * 32) % SEG;
-          const int koff = L::C >= 32 ? (((ks * 32) / SEG) * L::IW + rem / L::C) * L::CP + rem % L::C
-                                      : ((ks * 32) / SEG) * (L::IW * L::CP) + rem;
+          const int koff = L::C >= 32 ? ((ks * 32) / SEG) * RP + (rem / L::C) * L::CP + rem % L::C
+                                      : ((ks * 32) / SEG) * RP + rem;
           const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
           Atom<bf16>::mma(W[0][ks], b, acc0);
           Atom<bf16>::mma(W[1][ks], b, acc1);
@@ -211,16 +230,18 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
         out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
       } else {
         const int y = p / L::PW, x = p - y * L::PW;
-        const int base = s * LPATCH + (y * L::OW + x) * L::CP + fg * 8;
+        const int base = s * LPATCH + fg * 8;
         constexpr int KPT = L::OCK / 32; // k-steps per tap
 #pragma unroll
         for (int ks = 0; ks < L::KS; ++ks) {
           const int tap = ks / KPT, dy = tap / L::TW, dx = tap - dy * L::TW;
           const int sy = y - dy, sx = x - dx;
           const bool ok = qok && sy >= 0 && sy < L::OH && sx >= 0 && sx < L::OW;
-          // branch-free: always read (clamped to an in-range address), then zero invalid taps -> the
-          // compiler can issue all KS LDS reads ahead of the MFMAs
-          const int off = ok ? base - (dy * L::OW + dx) * L::CP + (ks % KPT) * 32 : fg * 8;
+          // branch-free: always read, then zero invalid taps -> the compiler can issue all KS LDS reads ahead
+          // of the MFMAs.  Invalid taps read the CLAMPED source pixel: the address then equals a neighbour
+          // lane's (broadcast) instead of piling every invalid lane onto one bank.
+          const int cy = min(max(sy, 0), L::OH - 1), cx = min(max(sx, 0), L::OW - 1);
+          const int off = base + cy * RP + cx * L::CP + (ks % KPT) * 32;
           u32x4 b = *reinterpret_cast<const u32x4 *>(pb + off);
           b = ok ? b : zero16();
           Atom<bf16>::mma(W[0][ks], b, acc0);
@@ -304,19 +325,20 @@ template <class L, class Store>
 __device__ __forceinline__ void act_phase(const bf16 *pb, const ActW<L> &W, float scale, int wave, int lane,
                                           Store store) {
   constexpr int MA = ActW<L>::MA, NL = ActW<L>::NL, NATOM = (L::PIX + 15) / 16, SEG = L::KW * L::C;
+  constexpr int RP = PatchGeom<L>::RP;
   const int og = wave % MA, pl = wave / MA, fr = lane & 15, fg = lane >> 4;
   const int oc0 = og * 16 + fg * 4;
   for (int atom = pl; atom < NATOM; atom += NL) {
     const int q = atom * 16 + fr;
     const bool qok = q < L::PIX;
     const int oy = q / L::OW, ox = q - oy * L::OW;
-    const int base = qok ? ((oy * L::S) * L::IW + ox * L::S) * L::CP + fg * 8 : fg * 8;
+    const int base = qok ? (oy * L::S) * RP + (ox * L::S) * L::CP + fg * 8 : fg * 8;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < L::KS; ++ks) {
       const int rem = (ks * 32) % SEG;
-      const int koff = L::C >= 32 ? (((ks * 32) / SEG) * L::IW + rem / L::C) * L::CP + rem % L::C
-                                  : ((ks * 32) / SEG) * (L::IW * L::CP) + rem;
+      const int koff = L::C >= 32 ? ((ks * 32) / SEG) * RP + (rem / L::C) * L::CP + rem % L::C
+                                  : ((ks * 32) / SEG) * RP + rem;
       const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
       Atom<bf16>::mma(W.w[ks], b, acc);
     }
@@ -326,7 +348,7 @@ __device__ __forceinline__ void act_phase(const bf16 *pb, const ActW<L> &W, floa
   }
 }
 
-constexpr int ACT_X_ELEMS = 84 * 84 * 4, ACT_A1_ELEMS = 400 * LConv2Fwd::CP, ACT_A2_ELEMS = 81 * LConv3Fwd::CP;
+constexpr int ACT_X_ELEMS = 84 * 84 * 4, ACT_A1_ELEMS = PatchGeom<LConv2Fwd>::SP, ACT_A2_ELEMS = PatchGeom<LConv3Fwd>::SP;
 constexpr size_t ACT_SMEM = (size_t)(ACT_X_ELEMS + ACT_A1_ELEMS + ACT_A2_ELEMS) * 2;
 
 __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
@@ -373,10 +395,16 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
     }
     __syncthreads();
     act_phase<LConv1Full>(sx, W1, 1.0f / 255.0f, wave, lane,
-                          [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s1 + q * LConv2Fwd::CP + oc) = v; });
+                          [&](int q, int oc, u32x2 v) {
+                            *reinterpret_cast<u32x2 *>(s1 + (q / 20) * PatchGeom<LConv2Fwd>::RP + (q % 20) * LConv2Fwd::CP +
+                                                       oc) = v;
+                          });
     __syncthreads();
     act_phase<LConv2FwdSmall>(s1, W2, 1.0f, wave, lane,
-                              [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(s2 + q * LConv3Fwd::CP + oc) = v; });
+                              [&](int q, int oc, u32x2 v) {
+                                *reinterpret_cast<u32x2 *>(s2 + (q / 9) * PatchGeom<LConv3Fwd>::RP +
+                                                           (q % 9) * LConv3Fwd::CP + oc) = v;
+                              });
     __syncthreads();
     bf16 *out = P.a3 + n * (long)(49 * 64);
     act_phase<LConv3FwdSmall>(s2, W3, 1.0f, wave, lane,
@@ -391,7 +419,7 @@ struct LConv2FwdW4 : LConv2Fwd {
   static constexpr int SB = 1;
 };
 struct LConv3FwdW4 : LConv3Fwd {
-  static constexpr int SB = 3;
+  static constexpr int SB = 2; // 2 x 29.5 KB x 2 buffers = 59 KB per workgroup, two workgroups per CU
 };
 struct LConv3DgradW4 : LConv3Dgrad {
   static constexpr int SB = 4;
@@ -400,7 +428,7 @@ struct LConv2DgradW4 : LConv2Dgrad {
   static constexpr int SB = 1;
 };
 template <class L> constexpr size_t conv_patch_smem() {
-  return (size_t)2 * ((L::SB * (L::IN_ELEMS / L::C * L::CP) + 63) / 64 * 64) * 2;
+  return (size_t)2 * ((L::SB * PatchGeom<L>::SP + 63) / 64 * 64) * 2;
 }
 
 // ================================================================================================

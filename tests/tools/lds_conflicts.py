@@ -1,0 +1,186 @@
+"""LDS bank-conflict simulator for the patch conv kernels' fragment reads (developer tool, not a test).
+
+Models gfx950 ds_read_b128: four fixed 16-lane groups, 64 banks x 4 B, one LDS cycle per group plus one per extra
+distinct address on a busy 16-byte slot.  Prints the mean LDS cycles per fragment read (4.0 = conflict-free) for
+pixel pitch CP, row padding and unit padding candidates; the winners are the CP / RPAD / SPAD constants in
+csrc/conv_patch.hpp.  Takes a few minutes (pure-Python brute force).
+"""
+import itertools
+G=[list(range(0,4))+list(range(12,16))+list(range(20,28)), list(range(4,12))+list(range(16,20))+list(range(28,32))]
+G+= [[l+32 for l in g] for g in G]
+def cyc(addrs):  # addrs per lane (bytes, 16B reads) -> LDS cycles
+    tot=0
+    for g in G:
+        banks={}
+        for l in g:
+            a=addrs[l]
+            if a is None: continue
+            slot=(a//16)%16
+            banks.setdefault(slot,set()).add(a)
+        tot+=max([len(v) for v in banks.values()] or [1])
+    return tot
+def fwd(PIX,OW,S,IW,C,KW,KS,SB,CP):
+    LP=(IW*IW if True else 0)
+    tot=0;n=0
+    NATOM=(SB*PIX+15)//16
+    SEG=KW*C
+    npix_in = None
+    for atom in range(NATOM):
+        for ks in range(KS):
+            rem=(ks*32)%SEG
+            koff=(((ks*32)//SEG)*IW+rem//C)*CP+rem%C if C>=32 else ((ks*32)//SEG)*(IW*CP)+rem
+            ad=[]
+            for lane in range(64):
+                fr=lane&15;fg=lane>>4
+                q=atom*16+fr
+                if q>=SB*PIX: ad.append(fg*16); continue
+                s=q//PIX;p=q%PIX;oy=p//OW;ox=p%OW
+                base=s*(IWH*IW*CP)+((oy*S)*IW+ox*S)*CP+fg*8
+                ad.append((base+koff)*2)
+            tot+=cyc(ad);n+=1
+    return tot/n
+def dgrad(PIX,PW,OH,OW,OCK,TW,KS,SB,CP):
+    tot=0;n=0
+    NATOM=(SB*PIX+15)//16
+    KPT=OCK//32
+    for atom in range(NATOM):
+        for ks in range(KS):
+            tap=ks//KPT;dy=tap//TW;dx=tap%TW
+            ad=[]
+            for lane in range(64):
+                fr=lane&15;fg=lane>>4
+                q=atom*16+fr
+                s=min(q//PIX,SB-1);p=q%PIX;y=p//PW;x=p%PW
+                sy=y-dy;sx=x-dx
+                ok=q<SB*PIX and 0<=sy<OH and 0<=sx<OW
+                base=s*(OH*OW*CP)+(y*OW+x)*CP+fg*8
+                off= base-(dy*OW+dx)*CP+(ks%KPT)*32 if ok else fg*8
+                ad.append(off*2)
+            tot+=cyc(ad);n+=1
+    return tot/n
+for CP in [32,40,48,56,64,72,80,88,96,104]:
+    IWH=20
+    r2=fwd(81,9,2,20,32,4,16,1,CP) if CP<64 or True else None
+    print('CP',CP,'conv2fwd %.2f'%r2, end=' ')
+    IWH=9
+    if CP>=64:
+        print('conv3fwd(SB4) %.2f'%fwd(49,7,1,9,64,3,18,4,CP), 'conv3dgrad(SB8) %.2f'%dgrad(81,9,7,7,64,3,18,8,CP),'conv2dgrad(SB1) %.2f'%dgrad(100,10,9,9,64,2,8,1,CP))
+    else: print()
+print("---- row-pitch search")
+def fwd2(PIX,OW,S,IW,C,KW,KS,SB,CP,RP,SP):
+    tot=0;n=0
+    NATOM=(SB*PIX+15)//16
+    SEG=KW*C
+    for atom in range(NATOM):
+        for ks in range(KS):
+            rem=(ks*32)%SEG
+            kh=(ks*32)//SEG; kw=rem//C; cc=rem%C
+            ad=[]
+            for lane in range(64):
+                fr=lane&15;fg=lane>>4
+                q=atom*16+fr
+                if q>=SB*PIX: ad.append(fg*16); continue
+                s=q//PIX;p=q%PIX;oy=p//OW;ox=p%OW
+                e=s*SP+(oy*S+kh)*RP+(ox*S+kw)*CP+cc+fg*8
+                ad.append(e*2)
+            tot+=cyc(ad);n+=1
+    return tot/n
+def dgrad2(PIX,PW,OH,OW,OCK,TW,KS,SB,CP,RP,SP):
+    tot=0;n=0
+    NATOM=(SB*PIX+15)//16
+    KPT=OCK//32
+    for atom in range(NATOM):
+        for ks in range(KS):
+            tap=ks//KPT;dy=tap//TW;dx=tap%TW
+            ad=[]
+            for lane in range(64):
+                fr=lane&15;fg=lane>>4
+                q=atom*16+fr
+                s=min(q//PIX,SB-1);p=q%PIX;y=p//PW;x=p%PW
+                sy=y-dy;sx=x-dx
+                ok=q<SB*PIX and 0<=sy<OH and 0<=sx<OW
+                off= s*SP+sy*RP+sx*CP+(ks%KPT)*32+fg*8 if ok else fg*8
+                ad.append(off*2)
+            tot+=cyc(ad);n+=1
+    return tot/n
+import sys
+best={}
+def search(name,f,C,IW,rows,SB,lim):
+    res=[]
+    for CP in range(C,C+33,8):
+        for rpad in range(0,65,8):
+            RP=IW*CP+rpad
+            for spad in ([0] if SB==1 else range(0,65,8)):
+                SP=rows*RP+spad
+                if SB*SP*2*2>lim: continue
+                res.append((f(CP,RP,SP),CP,rpad,spad,SB*SP*2))
+    res.sort()
+    print(name,res[:4])
+search('conv2fwd SB1',lambda CP,RP,SP:fwd2(81,9,2,20,32,4,16,1,CP,RP,SP),32,20,20,1,80*1024)
+search('conv3fwd SB4',lambda CP,RP,SP:fwd2(49,7,1,9,64,3,18,4,CP,RP,SP),64,9,9,4,80*1024)
+search('conv3dgrad SB8',lambda CP,RP,SP:dgrad2(81,9,7,7,64,3,18,8,CP,RP,SP),64,7,7,8,160*1024)
+search('conv2dgrad SB1',lambda CP,RP,SP:dgrad2(100,10,9,9,64,2,8,1,CP,RP,SP),64,9,9,1,40*1024)
+print('---- wide search')
+def search2(name,f,C,IW,rows,SB,lim):
+    res=[]
+    for CP in range(C,C+65,8):
+        for rpad in range(0,129,8):
+            RP=IW*CP+rpad
+            for spad in ([0] if SB==1 else range(0,129,16)):
+                SP=rows*RP+spad
+                if SB*SP*2*2>lim: continue
+                res.append((round(f(CP,RP,SP),2),CP,rpad,spad,SB*SP*2))
+    res.sort()
+    print(name,res[:5])
+search2('conv3fwd SB4',lambda CP,RP,SP:fwd2(49,7,1,9,64,3,18,4,CP,RP,SP),64,9,9,4,160*1024)
+search2('conv3fwd SB1',lambda CP,RP,SP:fwd2(49,7,1,9,64,3,18,1,CP,RP,SP),64,9,9,1,160*1024)
+search2('conv3dgrad SB8',lambda CP,RP,SP:dgrad2(81,9,7,7,64,3,18,8,CP,RP,SP),64,7,7,8,160*1024)
+search2('conv3dgrad SB4',lambda CP,RP,SP:dgrad2(81,9,7,7,64,3,18,4,CP,RP,SP),64,7,7,4,160*1024)
+search2('conv2dgrad SB1',lambda CP,RP,SP:dgrad2(100,10,9,9,64,2,8,1,CP,RP,SP),64,9,9,1,40*1024)
+print('---- dgrad transposed walk')
+def dgrad3(PIX,PW,OH,OW,OCK,TW,KS,SB,CP,RP,SP):
+    tot=0;n=0
+    NATOM=(SB*PIX+15)//16
+    KPT=OCK//32
+    for atom in range(NATOM):
+        for ks in range(KS):
+            tap=ks//KPT;dy=tap//TW;dx=tap%TW
+            ad=[]
+            for lane in range(64):
+                fr=lane&15;fg=lane>>4
+                q=atom*16+fr
+                s=min(q//PIX,SB-1);p=q%PIX;x=p//PW;y=p%PW
+                sy=y-dy;sx=x-dx
+                ok=q<SB*PIX and 0<=sy<OH and 0<=sx<OW
+                off= s*SP+sy*RP+sx*CP+(ks%KPT)*32+fg*8 if ok else fg*8
+                ad.append(off*2)
+            tot+=cyc(ad);n+=1
+    return tot/n
+search2('conv3dgrad SB8 T',lambda CP,RP,SP:dgrad3(81,9,7,7,64,3,18,8,CP,RP,SP),64,7,7,8,160*1024)
+search2('conv2dgrad SB1 T',lambda CP,RP,SP:dgrad3(100,10,9,9,64,2,8,1,CP,RP,SP),64,9,9,1,40*1024)
+print('---- dgrad clamped')
+def dgrad4(PIX,PW,OH,OW,OCK,TW,KS,SB,CP,RP,SP):
+    tot=0;n=0
+    NATOM=(SB*PIX+15)//16
+    KPT=OCK//32
+    for atom in range(NATOM):
+        for ks in range(KS):
+            tap=ks//KPT;dy=tap//TW;dx=tap%TW
+            ad=[]
+            for lane in range(64):
+                fr=lane&15;fg=lane>>4
+                q=min(atom*16+fr,SB*PIX-1)
+                s=q//PIX;p=q%PIX;y=p//PW;x=p%PW
+                sy=min(max(y-dy,0),OH-1);sx=min(max(x-dx,0),OW-1)
+                off= s*SP+sy*RP+sx*CP+(ks%KPT)*32+fg*8
+                ad.append(off*2)
+            tot+=cyc(ad);n+=1
+    return tot/n
+search2('conv3dgrad SB8 clamp',lambda CP,RP,SP:dgrad4(81,9,7,7,64,3,18,8,CP,RP,SP),64,7,7,8,160*1024)
+search2('conv2dgrad SB1 clamp',lambda CP,RP,SP:dgrad4(100,10,9,9,64,2,8,1,CP,RP,SP),64,9,9,1,40*1024)
+print('current CP72:', dgrad4(81,9,7,7,64,3,18,8,72,7*72,49*72), dgrad4(100,10,9,9,64,2,8,1,72,9*72,81*72))
+print('---- conv3fwd SB options (limit 80KB per WG)')
+for SB in (1,2,3):
+    search2('conv3fwd SB%d'%SB,lambda CP,RP,SP:fwd2(49,7,1,9,64,3,18,SB,CP,RP,SP),64,9,9,SB,80*1024)
+for SB in (4,8):
+    search2('conv3dgrad SB%d clamp'%SB,lambda CP,RP,SP:dgrad4(81,9,7,7,64,3,18,SB,CP,RP,SP),64,7,7,SB,160*1024)
