@@ -168,7 +168,8 @@ static const void *Pcw(const Ctx *c, ParamId id) {
 }
 
 // conv stack forward for ns samples addressed by map -> c->h
-static void net_forward(Ctx *c, SampleMap map, long ns) {
+// returns the number of split-K partial slabs of h (1 unless max_parts allows the pipelined fc kernel to split)
+static int net_forward(Ctx *c, SampleMap map, long ns, int max_parts = 1) {
   prof_begin(c, ALEPPO_K_CONV1_FWD);
   conv1_fwd(c->stream, c->prec, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, ns);
   prof_end(c, ALEPPO_K_CONV1_FWD);
@@ -179,8 +180,9 @@ static void net_forward(Ctx *c, SampleMap map, long ns) {
   conv3_fwd(c->stream, c->prec, c->a2, Pcw(c, P_W3), Pf(c, P_B3), c->a3, ns);
   prof_end(c, ALEPPO_K_CONV3_FWD);
   prof_begin(c, ALEPPO_K_FC_FWD);
-  fc_fwd(c->stream, c->prec, c->a3, Pcw(c, P_WFC), Pf(c, P_BFC), c->h, ns, c->H);
+  const int parts = fc_fwd(c->stream, c->prec, c->a3, Pcw(c, P_WFC), Pf(c, P_BFC), c->h, ns, c->H, max_parts);
   prof_end(c, ALEPPO_K_FC_FWD);
+  return parts;
 }
 
 static void refresh_compute_copies(Ctx *c) {
@@ -324,7 +326,7 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(dalloc(reinterpret_cast<char **>(&c->dz1), mb * A1_PIX * A1_C * ts));
   CK(dalloc(reinterpret_cast<char **>(&c->dz2), mb * A2_PIX * A2_C * ts));
   CK(dalloc(reinterpret_cast<char **>(&c->dz3), mb * FC_IN * ts));
-  CK(dalloc(&c->h, mb * H * 4));
+  CK(dalloc(&c->h, (size_t)FC_FWD_MAX_PARTS * mb * H * 4)); // up to FC_FWD_MAX_PARTS split-K slabs
   CK(dalloc(&c->hpart, (size_t)FC_SPLITS * E * H * 4));
   CK(dalloc(reinterpret_cast<char **>(&c->dh), mb * H * ts));
   CK(dalloc(&c->logits_b, mb * A * 4));
@@ -759,13 +761,13 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const int mi = ep * M + mb;
       const long n0 = (long)mb * B;
       const SampleMap map = train_map(c, n0);
-      net_forward(c, map, B);
+      const int hparts = net_forward(c, map, B, FC_FWD_MAX_PARTS);
       prof_begin(c, ALEPPO_K_HEAD);
       launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, c->oldlp_n + n0 * A, c->adv_n + n0,
                         c->ret_n + n0, c->mask_n + n0, c->mask_counts + mb, hp, c->dh, prec,
                         c->metric_ps + 0 * fs + (size_t)mi * B, c->metric_ps + 1 * fs + (size_t)mi * B,
                         c->metric_ps + 2 * fs + (size_t)mi * B, c->metric_ps + 3 * fs + (size_t)mi * B,
-                        c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr);
+                        c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr, hparts);
       prof_end(c, ALEPPO_K_HEAD);
       prof_begin(c, ALEPPO_K_FC_DGRAD);
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);

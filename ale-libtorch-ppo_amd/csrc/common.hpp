@@ -160,7 +160,7 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
                        const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                       long B, int H, int A, float *logits_out, float *values_out);
+                       long B, int H, int A, float *logits_out, float *values_out, int hparts = 1);
 struct ReduceSeg {
   const float *slab;
   int S;
@@ -203,7 +203,11 @@ void conv1_fwd(hipStream_t s, int prec, const uint32_t *obs, SampleMap map, cons
                long ns);
 void conv2_fwd(hipStream_t s, int prec, const void *a1, const void *W2, const float *b2, void *a2, long ns);
 void conv3_fwd(hipStream_t s, int prec, const void *a2, const void *W3, const float *b3, void *a3, long ns);
-void fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H);
+// returns the number of split-K partial slabs written to h ([parts][ns][H], slab 0 carries the bias); 1 unless
+// max_parts > 1 allows the pipelined bf16 kernel to split K (the consumer then adds the slabs)
+int fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H,
+           int max_parts = 1);
+constexpr int FC_FWD_MAX_PARTS = 4;
 void fc_fwd_splitk(hipStream_t s, int prec, const void *a3, const void *Wfc, float *hpart, long ns, int H);
 void fc_dgrad(hipStream_t s, int prec, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H);
 void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns);

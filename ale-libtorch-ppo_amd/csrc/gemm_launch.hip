@@ -3,6 +3,7 @@
 // weights [oc][(kh,kw,c)].  No vendor BLAS / MIOpen on this path.
 #include "common.hpp"
 #include "gemm.hpp"
+#include "gemm_pipe.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -54,6 +55,79 @@ static void conv3_fwd_t(hipStream_t s, const void *a2, const void *W3, const flo
   typename EP::P ep{static_cast<T *>(a3), b3, 64, 1.0f};
   hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 128, 64, 2, 2>), grid2(M, 128, 64, 64), dim3(256), 0, s, ap, bp,
                      ep, (int)M, 64, 576);
+}
+
+// ------------------------------------------------------------------ pipelined bf16 fc GEMMs (gemm_pipe.hpp)
+static int pipe_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      n = p.multiProcessorCount;
+    if (n <= 0)
+      n = 256;
+  }
+  return n;
+}
+template <int MODE, int NST> static void launch_pipe(hipStream_t s, const PipeParams &P) {
+  static bool once = false;
+  constexpr size_t sm = gemm_pipe_smem<MODE, NST>();
+  static_assert(sm <= 160 * 1024, "LDS budget");
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pipe_kernel<MODE, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    once = true;
+  }
+  hipLaunchKernelGGL((gemm_pipe_kernel<MODE, NST>), dim3(std::min(P.njobs, pipe_cus())), dim3(512), sm, s, P);
+}
+static bool use_pipe() { return tune("ALEPPO_FC_PIPE", 1) != 0; }
+// forward: h partial slabs [parts][ns][H]; parts chosen so that the jobs fill the CUs with the fewest rounds
+static int fc_fwd_pipe(hipStream_t s, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H,
+                       int max_parts) {
+  const int tm = (int)((ns + 127) / 128), tn = (H + 127) / 128, tiles = tm * tn, cus = pipe_cus();
+  int best = 1;
+  double best_t = 1e30;
+  for (int sp = 1; sp <= max_parts; ++sp) {
+    const double t = (double)((tiles * sp + cus - 1) / cus) / sp + 0.02 * sp; // rounds x K-share (+ slab traffic)
+    if (t < best_t - 1e-9) {
+      best_t = t;
+      best = sp;
+    }
+  }
+  PipeParams P{};
+  P.A = static_cast<const bf16 *>(a3);
+  P.lda = FC_IN;
+  P.B = static_cast<const bf16 *>(Wfc);
+  P.ldb = FC_IN;
+  P.M = (int)ns;
+  P.N = H;
+  P.tiles_m = tm;
+  P.tiles_n = tn;
+  P.nstages = FC_IN / 64;
+  P.splits = best;
+  P.njobs = tiles * best;
+  P.out_f32 = h;
+  P.bias = bfc;
+  launch_pipe<0, 4>(s, P); // ring depth 3 / 4 / 5 measured equal: the loop runs at the L2 -> LDS DMA rate
+  return best;
+}
+static void fc_dgrad_pipe(hipStream_t s, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H) {
+  PipeParams P{};
+  P.A = static_cast<const bf16 *>(dh);
+  P.lda = H;
+  P.B = static_cast<const bf16 *>(WfcT);
+  P.ldb = H;
+  P.M = (int)ns;
+  P.N = FC_IN;
+  P.tiles_m = (int)((ns + 127) / 128);
+  P.tiles_n = (FC_IN + 127) / 128;
+  P.nstages = H / 64;
+  P.splits = 1;
+  P.njobs = P.tiles_m * P.tiles_n;
+  P.out_bf16 = static_cast<bf16 *>(dz3);
+  P.gate = static_cast<const bf16 *>(a3);
+  launch_pipe<1, 4>(s, P);
 }
 template <class T>
 static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H) {
@@ -301,10 +375,16 @@ void conv3_fwd(hipStream_t s, int prec, const void *a2, const void *W3, const fl
     return patch_conv3_fwd(s, a2, W3, b3, a3, ns);
   DISPATCH(prec, conv3_fwd_t<float>(s, a2, W3, b3, a3, ns), conv3_fwd_t<bf16>(s, a2, W3, b3, a3, ns));
 }
-void fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H) {
+int fc_fwd(hipStream_t s, int prec, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H,
+           int max_parts) {
+  if (prec == ALEPPO_BF16 && ns > 256 && H % 64 == 0 && H >= 64 && use_pipe())
+    return fc_fwd_pipe(s, a3, Wfc, bfc, h, ns, H, std::max(1, std::min(max_parts, FC_FWD_MAX_PARTS)));
   DISPATCH(prec, fc_fwd_t<float>(s, a3, Wfc, bfc, h, ns, H), fc_fwd_t<bf16>(s, a3, Wfc, bfc, h, ns, H));
+  return 1;
 }
 void fc_dgrad(hipStream_t s, int prec, const void *dh, const void *WfcT, const void *a3, void *dz3, long ns, int H) {
+  if (prec == ALEPPO_BF16 && ns > 256 && H % 64 == 0 && H >= 4 * 64 && use_pipe()) // K = H: needs > NST - 1 k-stages
+    return fc_dgrad_pipe(s, dh, WfcT, a3, dz3, ns, H);
   DISPATCH(prec, fc_dgrad_t<float>(s, dh, WfcT, a3, dz3, ns, H), fc_dgrad_t<bf16>(s, dh, WfcT, a3, dz3, ns, H));
 }
 void conv3_dgrad(hipStream_t s, int prec, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {

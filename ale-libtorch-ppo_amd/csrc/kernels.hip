@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512) void head_train_kernel(
     const int *__restrict__ act, const float *__restrict__ oldlp, const float *__restrict__ adv,
     const float *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
     T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
-    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int abl) {
+    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts) {
   constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
   constexpr int NWV = 8;                // waves per workgroup
   extern __shared__ float smem[];
@@ -459,7 +459,13 @@ __global__ __launch_bounds__(512) void head_train_kernel(
 #pragma unroll
     for (int i = 0; i < HPL; ++i) {
       const int j = lane + 64 * i;
-      hnext[i] = (ok && j < H) ? h[(size_t)r * H + j] : 0.f;
+      float v = 0.f;
+      if (ok && j < H) { // h arrives as `hparts` split-K partial slabs [hparts][B][H] (slab 0 carries the bias)
+        v = h[(size_t)r * H + j];
+        for (int p = 1; p < hparts; ++p)
+          v += h[((size_t)p * B + r) * H + j];
+      }
+      hnext[i] = v;
     }
 #pragma unroll
     for (int a = 0; a < AMAX; ++a)
@@ -600,7 +606,6 @@ __global__ __launch_bounds__(512) void head_train_kernel(
   }
   // deterministic cross-wave reduction, one head row at a time: every wave writes its partial of row a, then
   // thread j adds the NWV partials of column j in fixed order and stores the workgroup's slab entry
-  (void)abl;
   float *sPart = sAcc; // [NWV][H] (reuses the accumulator region: (A+1)*H >= ... is not needed, H*NWV floats)
   float *ow = slab_w + (size_t)blockIdx.x * (A + 1) * H;
 #pragma unroll
@@ -635,20 +640,12 @@ __global__ __launch_bounds__(512) void head_train_kernel(
   }
 }
 
-static int head_abl() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = std::getenv("ALEPPO_HEAD_ABL");
-    v = e ? std::atoi(e) : 0;
-  }
-  return v;
-}
 template <class T>
 static void head_train_t(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
                          const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
                          const float *mask_count, Hyper hp, void *dh, float *ps_total, float *ps_clipped,
                          float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                         long B, int H, int A, float *lo, float *vo) {
+                         long B, int H, int A, float *lo, float *vo, int hparts) {
 #define LAUNCH_HEAD(AM)                                                                                                \
   do {                                                                                                                 \
     const size_t sm = ((size_t)((AM + 1) + ((AM + 1) > 8 ? (AM + 1) : 8)) * H + 8 * (AM + 1)) * sizeof(float);        \
@@ -657,7 +654,7 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
     hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(512), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
                        mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
-                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, head_abl());                                         \
+                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts);                                                 \
   } while (0)
   if (A <= 4)
     LAUNCH_HEAD(4);
@@ -671,13 +668,13 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
                        const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                       long B, int H, int A, float *logits_out, float *values_out) {
+                       long B, int H, int A, float *logits_out, float *values_out, int hparts) {
   if (prec == ALEPPO_BF16)
     head_train_t<bf16>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
-                       ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out);
+                       ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts);
   else
     head_train_t<float>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
-                        ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out);
+                        ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts);
 }
 
 // ================================================================================================
