@@ -40,7 +40,7 @@ template <bool RAW>
 __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__ frames, const uint8_t *__restrict__ lut,
                                                       const uint8_t *__restrict__ start, StartBits sbits, uint32_t *obs,
                                                       int slots, int t_src, int t_dst) {
-  // one thread per output pixel: every load of a thread (<= 18 raw bytes, the old packed pixel, the start flag)
+  // one thread per output pixel: every load of a thread (6 raw dwords, the old packed pixel, the start flag)
   // is independent and issued up front - one memory round trip, no staging barrier on the frame data; the
   // 256-entry LUT sits in LDS.  A wave's 64 adjacent output pixels read ~122 adjacent raw bytes per row.
   const int e = blockIdx.y, tid = threadIdx.x;
@@ -57,16 +57,18 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__
   if (RAW) {
     const int y0 = (i * RAW_H) / 84, x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84; // 3 rows, 2-3 cols
     const bool wide = (x1 - x0) == 3;
-    uint8_t rawb[2][3][3];
+    // ONE unaligned dword per (frame, row) instead of 2-3 byte loads: the kernel is bound by the number of
+    // vector-memory instructions (20 -> 8 per pixel).  The dword starts at min(x0, RAW_W - 4) so it never leaves
+    // the row; the wanted bytes are shifted down.
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    const int xa = min(x0, RAW_W - 4), sh = (x0 - xa) * 8;
+    uint32_t roww[2][3];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      const uint8_t *src = frames + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)y0 * RAW_W + x0;
+      const uint8_t *src = frames + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)y0 * RAW_W + xa;
 #pragma unroll
-      for (int y = 0; y < 3; ++y) {
-        rawb[f][y][0] = live ? src[y * RAW_W] : 0;
-        rawb[f][y][1] = live ? src[y * RAW_W + 1] : 0;
-        rawb[f][y][2] = (live && wide) ? src[y * RAW_W + 2] : 0;
-      }
+      for (int y = 0; y < 3; ++y)
+        roww[f][y] = live ? *reinterpret_cast<const u32_unaligned *>(src + y * RAW_W) : 0u;
     }
     slut[tid] = lut[tid];
     __syncthreads();
@@ -75,8 +77,10 @@ __global__ __launch_bounds__(256) void ingest_kernel(const uint8_t *__restrict__
     for (int f = 0; f < 2; ++f) {
       int s = 0;
 #pragma unroll
-      for (int y = 0; y < 3; ++y)
-        s += slut[rawb[f][y][0]] + slut[rawb[f][y][1]] + (wide ? slut[rawb[f][y][2]] : 0);
+      for (int y = 0; y < 3; ++y) {
+        const uint32_t w = roww[f][y] >> sh;
+        s += slut[w & 255u] + slut[(w >> 8) & 255u] + (wide ? slut[(w >> 16) & 255u] : 0);
+      }
       // adaptive-average (area) mean in f32 like interpolate(mode=area), round-half-even to u8
       const int q = (int)rintf((float)s / (wide ? 9.0f : 6.0f));
       best = max(best, q);
