@@ -222,19 +222,25 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
       values_t[e] = zmine;
     if (lane == 0) {
       actions_t[e] = best;
-      if (pinned)
-        pinned[e] = best;
+      if (pinned) // system-scope (sc0 sc1, write-through) store straight to the mapped host buffer
+        __hip_atomic_store(pinned + e, (int64_t)best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  if (done_ctr && pinned) { // publish: every storing wave makes its stores system-visible, the last arriver writes the ticket
-    __threadfence_system();
+  if (done_ctr && pinned) {
+    // Publish.  The host only needs the actions; they were written with system-scope stores, so a full
+    // system-scope release (an L2 write-back of everything this rollout slot dirtied, ~4 us) is not needed:
+    // every storing wave drains its stores (vmcnt(0): acknowledged), the workgroup meets, one thread bumps the
+    // device counter and the last arriver - which therefore runs after every wave's acknowledged stores - writes
+    // the ticket, again at system scope.  All atomics are RELAXED on purpose (an agent / system release would emit
+    // the buffer_wbl2 this path exists to avoid); the order comes from the explicit vmcnt(0) drain, the barrier and
+    // the data dependency of the ticket store on the counter's return value.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned int prev = atomicAdd(done_ctr, 1u);
+      const unsigned int prev = __hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (prev == gridDim.x - 1) {
-        *done_ctr = 0;
-        __threadfence_system();
-        *reinterpret_cast<volatile long long *>(pinned + E) = ticket;
+        __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<long long *>(pinned + E), ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
