@@ -133,14 +133,19 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int ks = 0; ks < L::KS; ++ks)
-      W[a][ks] = *reinterpret_cast<const u32x4 *>(P.w + (long)(wrow0 + a * 16 + fr) * K + ks * 32 + fg * 8);
-  const int oc0 = (L::CLASSES > 1 ? 0 : og * 32) + fg * 4; // first of this lane's 4 output channels (atom 0)
+      // Row fr of atom a is output channel (fr >> 2) * 8 + a * 4 + (fr & 3) of this wave's 32: the MFMA result then
+      // leaves lane (fr, fg) with channels fg * 8 + {0..3} (atom 0) and fg * 8 + {4..7} (atom 1) - 8 CONSECUTIVE
+      // channels, so every epilogue access is one 16-byte piece and the 4 lanes of a pixel cover 64 contiguous bytes
+      // (8-byte pieces at a 32-byte stride cost conv2 dgrad 40 of its 100 us in partial-line stores).
+      W[a][ks] = *reinterpret_cast<const u32x4 *>(
+          P.w + (long)(wrow0 + (fr >> 2) * 8 + a * 4 + (fr & 3)) * K + ks * 32 + fg * 8);
+  const int oc0 = (L::CLASSES > 1 ? 0 : og * 32) + fg * 8; // first of this lane's 8 consecutive output channels
   float bias_r[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      bias_r[a][r] = (L::MODE == PM_FWD) ? P.bias[oc0 + a * 16 + r] : 0.f;
+      bias_r[a][r] = (L::MODE == PM_FWD) ? P.bias[oc0 + a * 4 + r] : 0.f;
 
   // a "unit" is a sample (GPS == 1) or a half sample (conv1); a group is SB consecutive units
   const long nunits = P.ns * L::GPS;
@@ -213,6 +218,7 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
       const int s = min(q / L::PIX, L::SB - 1), p = q - (q / L::PIX) * L::PIX;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       long out_off;
+      u32x4 gate = zero16();
       if constexpr (L::MODE == PM_FWD) {
         const int oy = p / L::OW, ox = p - oy * L::OW;
         const int base = qok ? s * LPATCH + (oy * L::S) * RP + (ox * L::S) * L::CP + fg * 8 : fg * 8;
@@ -230,6 +236,16 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
         out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
       } else {
         const int y = p / L::PW, x = p - y * L::PW;
+        if constexpr (L::CLASSES > 1) { // conv2 dgrad: pixel (2y+py, 2x+px) of the 20x20x32 tensor
+          const int py = og >> 1, px = og & 1;
+          out_off = (((n0 + s) * 20 + 2 * y + py) * 20 + 2 * x + px) * (long)L::OUTC + oc0;
+        } else {
+          out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
+        }
+        // the ReLU gate is fetched BEFORE the MFMA chain: issued in the epilogue its full global-memory latency
+        // was exposed once per atom (PMC: 67 % of conv2 dgrad's wave cycles parked in s_waitcnt)
+        if (qok)
+          gate = *reinterpret_cast<const u32x4 *>(P.act + out_off);
         const int base = s * LPATCH + fg * 8;
         constexpr int KPT = L::OCK / 32; // k-steps per tap
 #pragma unroll
@@ -247,12 +263,6 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
           Atom<bf16>::mma(W[0][ks], b, acc0);
           Atom<bf16>::mma(W[1][ks], b, acc1);
         }
-        if constexpr (L::CLASSES > 1) { // conv2 dgrad: pixel (2y+py, 2x+px) of the 20x20x32 tensor
-          const int py = og >> 1, px = og & 1;
-          out_off = (((n0 + s) * 20 + 2 * y + py) * 20 + 2 * x + px) * (long)L::OUTC + oc0;
-        } else {
-          out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
-        }
       }
       if (qok) {
         if constexpr (L::MODE == PM_FWD) {
@@ -262,21 +272,18 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
             v0[r] = fmaxf(acc0[r] * P.scale + bias_r[0][r], 0.f);
             v1[r] = fmaxf(acc1[r] * P.scale + bias_r[1][r], 0.f);
           }
-          *reinterpret_cast<u32x2 *>(P.out + out_off) = pack4_bf16(v0[0], v0[1], v0[2], v0[3]);
-          *reinterpret_cast<u32x2 *>(P.out + out_off + 16) = pack4_bf16(v1[0], v1[1], v1[2], v1[3]);
+          const u32x2 lo = pack4_bf16(v0[0], v0[1], v0[2], v0[3]), hi = pack4_bf16(v1[0], v1[1], v1[2], v1[3]);
+          *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         } else {
-          const u32x2 m0 = *reinterpret_cast<const u32x2 *>(P.act + out_off);
-          const u32x2 m1 = *reinterpret_cast<const u32x2 *>(P.act + out_off + 16);
-          auto gate = [](uint32_t w, int hi, float v) { // ReLU gate on the stored bf16 activation
-            const float a = bf16_bits_to_f32(hi ? (w >> 16) : (w & 0xFFFFu));
+          auto gated = [](uint32_t w, int h, float v) { // ReLU gate on the stored bf16 activation
+            const float a = bf16_bits_to_f32(h ? (w >> 16) : (w & 0xFFFFu));
             return a > 0.f ? v : 0.f;
           };
-          *reinterpret_cast<u32x2 *>(P.out + out_off) =
-              pack4_bf16(gate(m0[0], 0, acc0[0]), gate(m0[0], 1, acc0[1]), gate(m0[1], 0, acc0[2]),
-                         gate(m0[1], 1, acc0[3]));
-          *reinterpret_cast<u32x2 *>(P.out + out_off + 16) =
-              pack4_bf16(gate(m1[0], 0, acc1[0]), gate(m1[0], 1, acc1[1]), gate(m1[1], 0, acc1[2]),
-                         gate(m1[1], 1, acc1[3]));
+          const u32x2 lo = pack4_bf16(gated(gate[0], 0, acc0[0]), gated(gate[0], 1, acc0[1]), gated(gate[1], 0, acc0[2]),
+                                      gated(gate[1], 1, acc0[3]));
+          const u32x2 hi = pack4_bf16(gated(gate[2], 0, acc1[0]), gated(gate[2], 1, acc1[1]), gated(gate[3], 0, acc1[2]),
+                                      gated(gate[3], 1, acc1[3]));
+          *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
       }
     }
