@@ -275,6 +275,8 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(hipEventCreateWithFlags(&c->ev_comm0, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_comm1, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_tmp, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_adam, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
   CK(dalloc(&c->obs, (size_t)E * (T + 1) * FRAME_PIX * 4));
   c->step_rec_bytes = ((size_t)7 * E + 15) / 16 * 16;
   CK(dalloc(&c->step_rec, c->step_rec_bytes * T));
@@ -335,7 +337,7 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   c->slab_off[0] = 0;
   const size_t sl[10] = {(size_t)MAXS_C1 * 32 * 256,       (size_t)MAXS_C1 * 32, (size_t)MAXS_C2 * 64 * 512,
                          (size_t)MAXS_C2 * 64,              (size_t)MAXS_C3 * 64 * 576, (size_t)MAXS_C3 * 64,
-                         (size_t)MAXS_FC * H * FC_IN,       (size_t)MAXS_FC * H, (size_t)MAXS_HEAD * (A + 1) * H,
+                         (size_t)MAXS_FC * H * FC_IN,       (size_t)MAXS_HEAD * H, (size_t)MAXS_HEAD * (A + 1) * H,
                          (size_t)MAXS_HEAD * (A + 1)};
   for (int i = 0; i < 10; ++i)
     c->slab_off[i + 1] = c->slab_off[i] + align64(sl[i]);
@@ -375,7 +377,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
       hipEventDestroy(pc.start[i]);
       hipEventDestroy(pc.stop[i]);
     }
-  for (hipEvent_t e : {c->ev_bucket0, c->ev_comm0, c->ev_comm1, c->ev_tmp})
+  for (hipEvent_t e : {c->ev_bucket0, c->ev_comm0, c->ev_comm1, c->ev_tmp, c->ev_adam, c->ev_pack})
     if (e)
       hipEventDestroy(e);
   if (c->stream)
@@ -756,37 +758,47 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   const int nblk_head = (int)std::min<long>(MAXS_HEAD, (B + 15) / 16);
   const int nblk_sq = (int)std::min<size_t>(1024, (L.total() + 4095) / 4096);
 
+  bool pack_pending = false;
   for (int ep = 0; ep < epochs; ++ep)
     for (int mb = 0; mb < M; ++mb) { // contiguous env-major slices; randperm unused (Q1)
       const int mi = ep * M + mb;
       const long n0 = (long)mb * B;
       const SampleMap map = train_map(c, n0);
       const int hparts = net_forward(c, map, B, FC_FWD_MAX_PARTS);
+      const bool wg_pipe = fc_wgrad_pipelined(prec, B, H); // then the head kernel also emits the fc bias gradient
       prof_begin(c, ALEPPO_K_HEAD);
       launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, c->oldlp_n + n0 * A, c->adv_n + n0,
                         c->ret_n + n0, c->mask_n + n0, c->mask_counts + mb, hp, c->dh, prec,
                         c->metric_ps + 0 * fs + (size_t)mi * B, c->metric_ps + 1 * fs + (size_t)mi * B,
                         c->metric_ps + 2 * fs + (size_t)mi * B, c->metric_ps + 3 * fs + (size_t)mi * B,
-                        c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr, hparts);
+                        c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr, hparts,
+                        wg_pipe ? sBfc : nullptr);
       prof_end(c, ALEPPO_K_HEAD);
+      if (pack_pending) { // the previous minibatch's repacked dgrad weights
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
+        pack_pending = false;
+      }
       prof_begin(c, ALEPPO_K_FC_DGRAD);
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
       prof_end(c, ALEPPO_K_FC_DGRAD);
       prof_begin(c, ALEPPO_K_FC_WGRAD);
       // split-K slabs (or, with one slice, straight into the gradient tensor)
-      const bool fc_direct = fc_wgrad_slices(prec, B) == 1;
+      const bool fc_direct = !wg_pipe && fc_wgrad_slices(prec, B) == 1;
       const int Sfc = fc_wgrad(s, prec, c->dh, c->a3, fc_direct ? c->G + L.off[P_WFC] : sWfc,
                                fc_direct ? c->G + L.off[P_BFC] : sBfc, B, H);
       prof_end(c, ALEPPO_K_FC_WGRAD);
-      prof_begin(c, ALEPPO_K_REDUCE);
-      {
-        const ReduceSeg segs[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
-                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]},
-                                   {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
-                                   {sBfc, Sfc, (long)H, (long)L.off[P_BFC]}};
-        launch_reduce_slabs(s, segs, fc_direct ? 2 : 4, c->G);
+      // bucket 0 = heads + fc.  With data parallelism it is reduced now so that its all-reduce overlaps the conv
+      // backward; on one GPU all ten slab groups are reduced by ONE launch after the conv wgrads.
+      const ReduceSeg segs0[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
+                                  {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]},
+                                  {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
+                                  {sBfc, wg_pipe ? nblk_head : Sfc, (long)H, (long)L.off[P_BFC]}};
+      const int nseg0 = fc_direct ? 2 : 4;
+      if (dp) {
+        prof_begin(c, ALEPPO_K_REDUCE);
+        launch_reduce_slabs(s, segs0, nseg0, c->G);
+        prof_end(c, ALEPPO_K_REDUCE);
       }
-      prof_end(c, ALEPPO_K_REDUCE);
       if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs
         HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
@@ -810,10 +822,14 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_end(c, ALEPPO_K_CONV1_WGRAD);
       prof_begin(c, ALEPPO_K_REDUCE);
       {
-        const ReduceSeg segs[6] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
-                                   {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]},
-                                   {sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
-        launch_reduce_slabs(s, segs, 6, c->G);
+        ReduceSeg segs[10] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
+                              {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]},
+                              {sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
+        int nseg = 6;
+        if (!dp)
+          for (int i = 0; i < nseg0; ++i)
+            segs[nseg++] = segs0[i];
+        launch_reduce_slabs(s, segs, nseg, c->G);
       }
       prof_end(c, ALEPPO_K_REDUCE);
       if (dp) {
@@ -833,9 +849,17 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, prec, (long)L.total(),
                   c->sumsq_part, nblk_sq, hp.max_norm, (float)(lr / bc1), (float)std::sqrt(bc2), (float)b1, (float)b2,
                   c->cfg.adam_eps, c->grad_norms + mi);
-      launch_pack_dgrad(s, c->P, L, c->W2d, c->W3d, c->WfcT, prec);
       prof_end(c, ALEPPO_K_ADAM);
+      // The dgrad weight layouts (W2d, W3d, WfcT) are first needed by the NEXT minibatch's fc dgrad: repack them
+      // on the side stream, off the critical path, while the next forward pass runs.
+      HIPCHK(c, hipEventRecord(c->ev_adam, s));
+      HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
+      launch_pack_dgrad(c->comm_stream, c->P, L, c->W2d, c->W3d, c->WfcT, prec);
+      HIPCHK(c, hipEventRecord(c->ev_pack, c->comm_stream));
+      pack_pending = true;
     }
+  if (pack_pending)
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
   HIPCHK(c, hipGetLastError());
   const int nm = epochs * M;
   launch_metrics_reduce(s, c->metric_ps, fs, c->mask_n, B, M, epochs, c->metric_red);

@@ -64,6 +64,7 @@ struct Ctx {
   std::string err;
   hipStream_t stream = nullptr, comm_stream = nullptr;
   hipEvent_t ev_bucket0 = nullptr, ev_comm0 = nullptr, ev_comm1 = nullptr, ev_tmp = nullptr;
+  hipEvent_t ev_adam = nullptr, ev_pack = nullptr; // adam done -> dgrad weight repack on the side stream -> done
   void *nccl_comm = nullptr;
 
   // ---- rollout storage (time-major scalars, env-major packed observation slots) ----
@@ -160,7 +161,8 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
                        const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                       long B, int H, int A, float *logits_out, float *values_out, int hparts = 1);
+                       long B, int H, int A, float *logits_out, float *values_out, int hparts = 1,
+                       float *slab_bfc = nullptr); // slab_bfc: [nblk][H] column sums of dh (fc bias gradient)
 struct ReduceSeg {
   const float *slab;
   int S;
@@ -215,6 +217,7 @@ void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, cons
 // wgrads write split-K slabs; return the number of slices S used (slab holds S*[M*N] then bias S*[M])
 int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *slab_w, float *slab_b, long ns, int H);
 int fc_wgrad_slices(int prec, long ns); // number of split-K slices fc_wgrad will use for ns samples
+bool fc_wgrad_pipelined(int prec, long ns, int H); // pipelined kernel: no bias slab (head_train_kernel sums dh)
 int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float *slab_w, float *slab_b, long ns);
 int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *slab_w, float *slab_b, long ns);
 int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *slab_w,

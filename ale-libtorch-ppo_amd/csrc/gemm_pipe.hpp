@@ -29,6 +29,13 @@
 //        tile is DMA'd into LDS like a stage (an ordinary global load would make hipcc drain the DMA queue),
 //        gated in place and written back with whole 256-byte rows.  Needs >= NST k-stages per job.
 //
+// MODE 2 (fc wgrad): C[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands k-major (A = dh [samples][H],
+//        B = a3 [samples][3136]), split-K fp32 slabs [splits][M][N].  A stage is 64 samples: tiles land in LDS as
+//        [k][128 columns] (256-byte rows, XOR-swizzled on the DMA source: slot s of row k holds 16-byte column chunk
+//        s ^ (((k & 3) << 2) | ((k >> 2) & 3))), and the MFMA operands are gathered with ds_read_b64_tr_b16: two
+//        transposed 4-row blocks per fragment, the two 16-lane groups of a half-wave 8 rows apart (conflict-free).
+//        Both operands use the same lane -> k map, so the permutation of the 32 k's of a step cancels.
+//
 // Wait-count rule used throughout: `s_waitcnt vmcnt(N)` is safe iff N <= the number of vector-memory
 // instructions this wave ISSUED after the batch it needs (they retire in issue order).  Under-counting only
 // waits longer; epilogue stores are therefore counted only when no wave-instruction can be fully masked off.
@@ -91,15 +98,21 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
   const int slot = tid & 7, r0 = tid >> 3;    // stage DMA: this thread moves slot `slot` of rows r0 and r0 + 64
   const int eslot = tid & 15, er0 = tid >> 4; // gate / output tile: slot eslot of rows er0 + 32 i
 
-  // Job -> workgroup map.  Workgroup b runs on XCD b % 8 (round-robin dispatch; a speed assumption only).  When the
-  // m-tiles divide by 8 every XCD owns tiles_m / 8 row panels and its workgroups sweep the n-tiles together, so the
-  // operand panels an XCD touches at any time (a few A and a few B panels) stay inside its 4 MB L2.
-  const bool xmap = P.tiles_m % 8 == 0 && gridDim.x % 8 == 0;
-  const int tmx = xmap ? P.tiles_m / 8 : P.tiles_m;              // m-tiles per job group
-  const int jobs_g = tmx * P.tiles_n * P.splits;                  // jobs per group (XCD)
-  const int wg_l = xmap ? (int)blockIdx.x / 8 : (int)blockIdx.x; // this workgroup within its group
-  const int nwg_l = xmap ? (int)gridDim.x / 8 : (int)gridDim.x;
-  const int tm_base = xmap ? ((int)blockIdx.x % 8) * tmx : 0;
+  // Job -> workgroup map.  Workgroup b runs on XCD b % 8 (round-robin dispatch; a speed assumption only); jobs are
+  // grouped so that the operand panels an XCD touches at any time stay inside its 4 MB L2.
+  // Two XCD-grouped maps: (x) m-tiles divide by 8 -> every XCD owns tiles_m / 8 row panels and its workgroups sweep the
+  // n-tiles together; (p) otherwise the (n-tile, slice) pairs are dealt round-robin to the XCDs and the m-tiles of a
+  // pair run side by side on one XCD, sharing that pair's B stream (the wgrad: 4 m-tiles re-use each a3 tile).
+  const bool grouped = gridDim.x % 8 == 0;
+  const bool xmap = grouped && P.tiles_m % 8 == 0, pmap = grouped && !xmap;
+  const int xcd = (int)blockIdx.x % 8;
+  const int tmx = xmap ? P.tiles_m / 8 : P.tiles_m; // m-tiles per job group
+  const int npairs = P.tiles_n * P.splits;
+  const int pairs_g = pmap ? (npairs - xcd + 7) / 8 : npairs;          // (n-tile, slice) pairs of this group
+  const int jobs_g = tmx * pairs_g;                                     // jobs of this group
+  const int wg_l = grouped ? (int)blockIdx.x / 8 : (int)blockIdx.x;     // this workgroup within its group
+  const int nwg_l = grouped ? (int)gridDim.x / 8 : (int)gridDim.x;
+  const int tm_base = xmap ? xcd * tmx : 0;
   const int nj = (jobs_g - wg_l + nwg_l - 1) / nwg_l; // jobs of this workgroup
   if (nj <= 0)
     return;
@@ -108,7 +121,18 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
   };
   auto decode = [&](int ord) {
     const int j = wg_l + ord * nwg_l;
-    const int slice = j % P.splits, t = j / P.splits, tm = tm_base + t % tmx, tn = t / tmx;
+    int slice, tm, tn;
+    if (pmap) { // m-tile fastest, then this group's pairs
+      const int pr = xcd + 8 * (j / tmx);
+      tm = j % tmx;
+      slice = pr % P.splits;
+      tn = pr / P.splits;
+    } else {
+      slice = j % P.splits;
+      const int t = j / P.splits;
+      tm = tm_base + t % tmx;
+      tn = t / tmx;
+    }
     const int ks0 = (int)((long)slice * P.nstages / P.splits), ks1 = (int)((long)(slice + 1) * P.nstages / P.splits);
     return Job{tm * 128, tn * 128, slice, ks0, ks1 - ks0};
   };
@@ -124,19 +148,26 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
   auto set_src = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = r0 + 64 * i, sw = (slot ^ (r & 7)) * 8;
-      pa[i] = P.A + (long)min(pjob.m0 + r, P.M - 1) * P.lda + (long)pjob.ks0 * 64 + sw;
-      pb[i] = P.B + (long)min(pjob.n0 + r, P.N - 1) * P.ldb + (long)pjob.ks0 * 64 + sw;
+      if constexpr (MODE == 2) { // rows are k (64 per stage), 16 column chunks per row
+        const int r = er0 + 32 * i, ch = eslot ^ (((r & 3) << 2) | ((r >> 2) & 3));
+        pa[i] = P.A + ((long)pjob.ks0 * 64 + r) * P.lda + min(pjob.m0 + ch * 8, P.M - 8);
+        pb[i] = P.B + ((long)pjob.ks0 * 64 + r) * P.ldb + min(pjob.n0 + ch * 8, P.N - 8);
+      } else {
+        const int r = r0 + 64 * i, sw = (slot ^ (r & 7)) * 8;
+        pa[i] = P.A + (long)min(pjob.m0 + r, P.M - 1) * P.lda + (long)pjob.ks0 * 64 + sw;
+        pb[i] = P.B + (long)min(pjob.n0 + r, P.N - 1) * P.ldb + (long)pjob.ks0 * 64 + sw;
+      }
     }
   };
   set_src();
   // one batch = 4 LDS-DMA instructions per wave (pieces 0,1: A rows r0, r0 + 64; 2,3: B rows), then advance()
   auto piece = [&](int q) {
     u32x4 *dst = ring + pbuf * PIPE_STAGE_CHUNKS + wave * 64;
+    const long ka = MODE == 2 ? (long)pk * 64 * P.lda : (long)pk * 64, kb = MODE == 2 ? (long)pk * 64 * P.ldb : (long)pk * 64;
     if (q < 2)
-      __builtin_amdgcn_global_load_lds((gptr)(pa[q] + pk * 64), (lptr)(dst + 512 * q), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(pa[q] + ka), (lptr)(dst + 512 * q), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gptr)(pb[q - 2] + pk * 64), (lptr)(dst + 1024 + 512 * (q - 2)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(pb[q - 2] + kb), (lptr)(dst + 1024 + 512 * (q - 2)), 16, 0, 0);
   };
   auto advance = [&]() {
     pbuf = pbuf + 1 == NST ? 0 : pbuf + 1;
@@ -149,13 +180,34 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
   };
 
   // fragment reads of the stage in ring buffer `buf`
+  // MODE 2: transposed gather.  Lane (i = lane & 15, g = lane >> 4), q = i >> 2, p = i & 3 supplies the address of
+  // 4 columns of row (32 kc + 8 (g & 1) + 16 (g >> 1) + q) for the first block and 4 rows below for the second.
+  const int tq = fr >> 2, tp = fr & 3;
+  const int trow = 8 * (fg & 1) + 16 * (fg >> 1) + tq;
+  const int tsw1 = ((tq << 2) | (2 * (fg & 1))) ^ (tp >> 1), tsw2 = tsw1 ^ 1; // chunk = c0 ^ tsw (c0 even)
+  typedef __attribute__((address_space(3))) bf16x4 *lds4;
+  auto read_tr = [&](const uint8_t *tile, int kc, int c0) {
+    const uint8_t *p1 = tile + (kc * 32 + trow) * 256 + ((c0 ^ tsw1) * 16) + 8 * (tp & 1);
+    const uint8_t *p2 = tile + (kc * 32 + trow + 4) * 256 + ((c0 ^ tsw2) * 16) + 8 * (tp & 1);
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p1));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p2));
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
   auto read_a = [&](PipeFrags &f, int buf, int kc, int i) {
-    const int r = wm * 64 + i * 16 + fr;
-    f.a[kc][i] = ring[buf * PIPE_STAGE_CHUNKS + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
+    if constexpr (MODE == 2) {
+      f.a[kc][i] = read_tr(smem + (size_t)buf * PIPE_STAGE_CHUNKS * 16, kc, wm * 8 + i * 2);
+    } else {
+      const int r = wm * 64 + i * 16 + fr;
+      f.a[kc][i] = ring[buf * PIPE_STAGE_CHUNKS + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
+    }
   };
   auto read_b = [&](PipeFrags &f, int buf, int kc, int j) {
-    const int r = wn * 32 + j * 16 + fr;
-    f.b[kc][j] = ring[buf * PIPE_STAGE_CHUNKS + 1024 + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
+    if constexpr (MODE == 2) {
+      f.b[kc][j] = read_tr(smem + ((size_t)buf * PIPE_STAGE_CHUNKS + 1024) * 16, kc, wn * 4 + j * 2);
+    } else {
+      const int r = wn * 32 + j * 16 + fr;
+      f.b[kc][j] = ring[buf * PIPE_STAGE_CHUNKS + 1024 + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
+    }
   };
 
   f32x4 acc[4][2];
@@ -252,13 +304,13 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
     }
     if (++ck == cjob.nks) { // ---------------- epilogue of this job
       const int mrow = cjob.m0 + wm * 64 + fr, ncol = cjob.n0 + wn * 32 + fg * 4;
-      if constexpr (MODE == 0) {
+      if constexpr (MODE == 0 || MODE == 2) {
         float *out = P.out_f32 + (long)cjob.slice * P.M * P.N;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = ncol + j * 16;
           f32x4 b = {0.f, 0.f, 0.f, 0.f};
-          if (cjob.slice == 0 && n < P.N)
+          if (MODE == 0 && cjob.slice == 0 && n < P.N)
             b = *reinterpret_cast<const f32x4 *>(P.bias + n);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {

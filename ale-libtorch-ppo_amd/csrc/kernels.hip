@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512) void head_train_kernel(
     const int *__restrict__ act, const float *__restrict__ oldlp, const float *__restrict__ adv,
     const float *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
     T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
-    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts) {
+    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc) {
   constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
   constexpr int NWV = 8;                // waves per workgroup
   extern __shared__ float smem[];
@@ -490,7 +490,10 @@ __global__ __launch_bounds__(512) void head_train_kernel(
     sW[i] = Wh[i];
   __syncthreads();
   const float inv_nm = 1.0f / mask_count[0];
-  float gW[A1][HPL], gb[A1];
+  float gW[A1][HPL], gb[A1], gfc[HPL]; // gfc: column sums of dh = the fc bias gradient (when slab_bfc is given)
+#pragma unroll
+  for (int i = 0; i < HPL; ++i)
+    gfc[i] = 0.f;
 #pragma unroll
   for (int a = 0; a < A1; ++a) {
     gb[a] = 0.f;
@@ -607,7 +610,9 @@ __global__ __launch_bounds__(512) void head_train_kernel(
             d += dz[a] * sW[a * H + j];
             gW[a][i] += dz[a] * hv[i];
           }
-        dh[(size_t)row * H + j] = (T)d;
+        const T dr = (T)d;
+        dh[(size_t)row * H + j] = dr;
+        gfc[i] += (float)dr; // the rounded value the fc wgrad GEMM multiplies with
       }
     }
 #pragma unroll
@@ -648,6 +653,22 @@ __global__ __launch_bounds__(512) void head_train_kernel(
       sb += sB[w * A1 + tid];
     slab_b[(size_t)blockIdx.x * (A + 1) + tid] = sb;
   }
+  if (slab_bfc) { // same fixed-order cross-wave reduction for the fc bias gradient
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) {
+      const int j = lane + 64 * i;
+      if (j < H)
+        sPart[wave * H + j] = gfc[i];
+    }
+    __syncthreads();
+    for (int j = tid; j < H; j += 64 * NWV) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w)
+        sum += sPart[w * H + j];
+      slab_bfc[(size_t)blockIdx.x * H + j] = sum;
+    }
+  }
 }
 
 template <class T>
@@ -655,7 +676,7 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
                          const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
                          const float *mask_count, Hyper hp, void *dh, float *ps_total, float *ps_clipped,
                          float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                         long B, int H, int A, float *lo, float *vo, int hparts) {
+                         long B, int H, int A, float *lo, float *vo, int hparts, float *slab_bfc) {
 #define LAUNCH_HEAD(AM)                                                                                                \
   do {                                                                                                                 \
     const size_t sm = ((size_t)((AM + 1) + ((AM + 1) > 8 ? (AM + 1) : 8)) * H + 8 * (AM + 1)) * sizeof(float);        \
@@ -664,7 +685,7 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
     hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(512), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
                        mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
-                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts);                                                 \
+                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts, slab_bfc);                                         \
   } while (0)
   if (A <= 4)
     LAUNCH_HEAD(4);
@@ -678,13 +699,13 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
                        const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                       long B, int H, int A, float *logits_out, float *values_out, int hparts) {
+                       long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc) {
   if (prec == ALEPPO_BF16)
     head_train_t<bf16>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
-                       ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts);
+                       ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts, slab_bfc);
   else
     head_train_t<float>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
-                        ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts);
+                        ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts, slab_bfc);
 }
 
 // ================================================================================================

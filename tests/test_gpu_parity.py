@@ -298,6 +298,7 @@ def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M):
     try:
         for pipe in ("0", "1"):
             os.environ["ALEPPO_FC_PIPE"] = pipe
+            os.environ["ALEPPO_FC_PIPE_WGRAD"] = pipe  # the opt-in pipelined wgrad (transposed LDS gathers) too
             eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
             eng.load_params(params)
             eng.set_batch(obs, actions, old_lp, adv, ret, masks)
@@ -306,6 +307,7 @@ def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M):
             eng.close()
     finally:
         os.environ.pop("ALEPPO_FC_PIPE", None)
+        os.environ.pop("ALEPPO_FC_PIPE_WGRAD", None)
     (m0, g0, p0), (m1, g1, p1) = res["0"], res["1"]
     np.testing.assert_allclose(m1["loss"], m0["loss"], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(m1["grad_norm"], m0["grad_norm"], rtol=5e-3)
