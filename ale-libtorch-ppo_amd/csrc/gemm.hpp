@@ -498,7 +498,7 @@ template <> struct KFrag<bf16> {
 template <class T, class AL, class BL, int BM, int BN, int WM, int WN, bool BIAS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typename BL::P bp, float *slab,
                                                        float *bias_slab, int M, int N, int Ktot, int kchunk,
-                                                       float out_scale) {
+                                                       float out_scale, int xcd_swizzle) {
   using AT = Atom<T>;
   constexpr int VE = AT::VE, KP = AT::KT; // pixels per stage
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -512,7 +512,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  // Workgroups are dealt round-robin to the 8 XCDs in linear block order.  The gridDim.x m-tiles that share one
+  // (n-tile, slice) B stream would land on 8 different L2s and each fetch it again (PMC: 211 MB fetched for 30 MB
+  // of fc wgrad operands); with xcd_swizzle every XCD takes a CONTIGUOUS chunk of the work list instead, so
+  // those m-tiles run side by side on one XCD.  (Needs a block count that is a multiple of 8.)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (xcd_swizzle) {
+    const int lin = bx + gridDim.x * (by + gridDim.y * bz), per = (gridDim.x * gridDim.y * gridDim.z) / 8;
+    const int w = (lin % 8) * per + lin / 8;
+    bx = w % gridDim.x;
+    by = (w / gridDim.x) % gridDim.y;
+    bz = w / (gridDim.x * gridDim.y);
+  }
+  const int m0 = bx * BM, n0 = by * BN, z = bz;
   const int kbeg = z * kchunk, kend = min(Ktot, kbeg + kchunk);
   const int pl = tid / TPR, tv = tid % TPR; // this thread stages pixel row pl of every stage
 

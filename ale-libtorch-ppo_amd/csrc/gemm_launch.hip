@@ -332,18 +332,23 @@ template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const vo
   const int kc = chunk_for(ns, S, KP);
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
+  // contiguous per-XCD work chunks (the m-tiles sharing an a3 stream on one L2) when the block count allows
+  auto swz = [&](const dim3 &g) { return ((g.x * g.y * S) % 8 == 0 && tune("ALEPPO_TN_XCD", 1)) ? 1 : 0; };
   if (v == 1) {
     const dim3 g = grid2(H, 64, FC_IN, 64);
+    const int xsw = swz(g);
     hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
-                       sb, H, FC_IN, (int)ns, kc, 1.0f);
+                       sb, H, FC_IN, (int)ns, kc, 1.0f, xsw);
   } else if (v == 2) {
     const dim3 g = grid2(H, 128, FC_IN, 64);
+    const int xsw = swz(g);
     hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 128, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp,
-                       sw, sb, H, FC_IN, (int)ns, kc, 1.0f);
+                       sw, sb, H, FC_IN, (int)ns, kc, 1.0f, xsw);
   } else {
     const dim3 g = grid2(H, 64, FC_IN, 128);
+    const int xsw = swz(g);
     hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp,
-                       sw, sb, H, FC_IN, (int)ns, kc, 1.0f);
+                       sw, sb, H, FC_IN, (int)ns, kc, 1.0f, xsw);
   }
   return S;
 }
@@ -358,7 +363,7 @@ template <class T> static int conv3_wgrad_t(hipStream_t s, const void *dz3, cons
   typename AL::P ap{static_cast<const T *>(dz3), 64, 0};
   typename BL::P bp{static_cast<const T *>(a2), 1, 81 * 64, 0, 0, 0};
   hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
-                     sb, 64, 576, (int)K, kc, 1.0f);
+                     sb, 64, 576, (int)K, kc, 1.0f, 0);
   return S;
 }
 template <class T> static int conv2_wgrad_t(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns) {
@@ -372,7 +377,7 @@ template <class T> static int conv2_wgrad_t(hipStream_t s, const void *dz2, cons
   typename AL::P ap{static_cast<const T *>(dz2), 64, 0};
   typename BL::P bp{static_cast<const T *>(a1), 1, 400 * 32, 0, 0, 0};
   hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
-                     sb, 64, 512, (int)K, kc, 1.0f);
+                     sb, 64, 512, (int)K, kc, 1.0f, 0);
   return S;
 }
 template <class T>
@@ -388,7 +393,7 @@ static int conv1_wgrad_t(hipStream_t s, const void *dz1, const uint32_t *obs, Sa
   typename AL::P ap{static_cast<const T *>(dz1), 32, 0};
   typename BL::P bp{reinterpret_cast<const uint8_t *>(obs), map.TP, map.s1 * 4, map.s0 * 4, map.base * 4, map.n0};
   hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 32, 128, 1, 4, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
-                     sb, 32, 256, (int)K, kc, 1.0f / 255.0f);
+                     sb, 32, 256, (int)K, kc, 1.0f / 255.0f, 0);
   return S;
 }
 
