@@ -60,13 +60,15 @@ struct LConv3Dgrad {
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
-                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72, RPAD = 80, SPAD = 0;
+                       SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72, RPAD = 80, SPAD = 0,
+                       PRELOAD_GATES = 0;
 };
 struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
-                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 80, RPAD = 80, SPAD = 0;
+                       SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 80, RPAD = 80, SPAD = 0,
+                       PRELOAD_GATES = 0;
 };
 
 // LDS image of one unit: pixel (row, col) of the source at row*RP + col*CP bf16 elements, units SP apart.  The pixel
@@ -78,6 +80,17 @@ template <class L> constexpr int patch_src_width() { // source row width in pixe
     return L::IW;
   else
     return L::OW;
+}
+// dgrad descriptors may ask for the ReLU gates of ALL atoms of a group to be requested before its first MFMA
+// (PRELOAD_GATES = 1) and the atom loop to be unrolled: the loop is then free of loads, so hipcc no longer drains
+// the vector-memory queue (the previous atom's store + this atom's gate, a full memory round trip) once per atom.
+// conv2 dgrad: 90 -> 55 us at HALF the occupancy (196 VGPRs, 2 workgroups per CU).  conv3 dgrad (18 k-steps of
+// weights in registers) has no room for it: 2 samples per group measured equal, 4 spill.
+template <class L> constexpr bool preload_gates() {
+  if constexpr (L::MODE == PM_FWD)
+    return false;
+  else
+    return L::PRELOAD_GATES != 0;
 }
 template <class L> struct PatchGeom {
   static constexpr int IWL = patch_src_width<L>();
@@ -212,13 +225,32 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
     const bf16 *pb = sbuf + (size_t)(it & 1) * BUF_ELEMS;
     const long n0 = grp * L::SB; // first unit of this group; unit u covers output pixels [u*PIX, (u+1)*PIX)
     const int count = (int)min((long)L::SB, nunits - n0);
-    for (int atom = pl; atom < NATOM; atom += NL) {
+    constexpr int APW = (NATOM + NL - 1) / NL; // atoms per wave and group
+    constexpr bool PRE = L::MODE != PM_FWD && preload_gates<L>();
+    u32x4 gates[PRE ? APW : 1];
+    if constexpr (PRE) {
+#pragma unroll
+      for (int ak = 0; ak < APW; ++ak) {
+        const int a_ = pl + ak * NL, q_ = a_ * 16 + fr;
+        const int s_ = min(q_ / L::PIX, L::SB - 1), p_ = q_ - (q_ / L::PIX) * L::PIX;
+        const int y_ = p_ / L::PW, x_ = p_ - y_ * L::PW;
+        long off_;
+        if constexpr (L::CLASSES > 1)
+          off_ = (((n0 + s_) * 20 + 2 * y_ + (og >> 1)) * 20 + 2 * x_ + (og & 1)) * (long)L::OUTC + oc0;
+        else
+          off_ = ((n0 + s_) * L::PIX + p_) * (long)L::OUTC + oc0;
+        gates[ak] = zero16();
+        if (a_ < NATOM && q_ < count * L::PIX)
+          gates[ak] = *reinterpret_cast<const u32x4 *>(P.act + off_);
+      }
+    }
+    auto atom_body = [&](int atom, u32x4 gate_pre) {
       const int q = atom * 16 + fr;
       const bool qok = q < count * L::PIX;
       const int s = min(q / L::PIX, L::SB - 1), p = q - (q / L::PIX) * L::PIX;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       long out_off;
-      u32x4 gate = zero16();
+      u32x4 gate = gate_pre;
       if constexpr (L::MODE == PM_FWD) {
         const int oy = p / L::OW, ox = p - oy * L::OW;
         const int base = qok ? s * LPATCH + (oy * L::S) * RP + (ox * L::S) * L::CP + fg * 8 : fg * 8;
@@ -244,8 +276,9 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
         }
         // the ReLU gate is fetched BEFORE the MFMA chain: issued in the epilogue its full global-memory latency
         // was exposed once per atom (PMC: 67 % of conv2 dgrad's wave cycles parked in s_waitcnt)
-        if (qok)
-          gate = *reinterpret_cast<const u32x4 *>(P.act + out_off);
+        if constexpr (!PRE)
+          if (qok)
+            gate = *reinterpret_cast<const u32x4 *>(P.act + out_off);
         const int base = s * LPATCH + fg * 8;
         constexpr int KPT = L::OCK / 32; // k-steps per tap
 #pragma unroll
@@ -286,6 +319,15 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
           *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
       }
+    };
+    if constexpr (PRE) {
+#pragma unroll
+      for (int ak = 0; ak < APW; ++ak)
+        if (pl + ak * NL < NATOM)
+          atom_body(pl + ak * NL, gates[ak]);
+    } else {
+      for (int atom = pl; atom < NATOM; atom += NL)
+        atom_body(atom, zero16());
     }
     swrite((it + 1) & 1);
     gload(grp + 2 * (long)gridDim.x);
@@ -431,8 +473,9 @@ struct LConv3FwdW4 : LConv3Fwd {
 struct LConv3DgradW4 : LConv3Dgrad {
   static constexpr int SB = 4;
 };
+
 struct LConv2DgradW4 : LConv2Dgrad {
-  static constexpr int SB = 1;
+  static constexpr int SB = 1, PRELOAD_GATES = 1;
 };
 template <class L> constexpr size_t conv_patch_smem() {
   return (size_t)2 * ((L::SB * PatchGeom<L>::SP + 63) / 64 * 64) * 2;

@@ -77,7 +77,7 @@ void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const vo
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
   PatchParams P{dz2, static_cast<const bf16 *>(W2d), nullptr, static_cast<const bf16 *>(a1), static_cast<bf16 *>(dz1),
                 ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
-  launch_patch<LConv2DgradW4, 4, 4>(s, P);
+  launch_patch<LConv2DgradW4, 4, 2>(s, P); // 2 per CU: the preloaded gates take the kernel to 196 VGPRs
 }
 
 void patch_act_convs(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
