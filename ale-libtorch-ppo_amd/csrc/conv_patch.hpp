@@ -192,7 +192,7 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
       if (v < SRC_VECS) {
         if constexpr (U8) { // 16 bytes -> 16 bf16 (exact), two LDS vectors
           auto pk = [](uint32_t lo, uint32_t hi) {
-            return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+            return pack_u8_pair_bf16(lo, hi);
           };
           u32x4 o0, o1;
 #pragma unroll
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
       const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base;
       const u32x4 *src = reinterpret_cast<const u32x4 *>(P.obs + off);
       auto pk = [](uint32_t lo, uint32_t hi) {
-        return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+        return pack_u8_pair_bf16(lo, hi);
       };
       u32x4 R[4];
 #pragma unroll
@@ -602,7 +602,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
       if (v < XV) {
         if constexpr (U8) {
           auto pk = [](uint32_t lo, uint32_t hi) {
-            return (__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xFFFF0000u);
+            return pack_u8_pair_bf16(lo, hi);
           };
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
