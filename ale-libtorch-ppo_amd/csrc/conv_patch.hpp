@@ -487,17 +487,17 @@ template <class L> constexpr size_t conv_patch_smem() {
 struct LConv1Wgrad { // half-sample units like LConv1Fwd
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OC = 32, NJ = 256,
-                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4; // wave: 2 oc x 2 of 16 j atoms
+                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, PF2 = 1; // wave: 2 oc x 2 of 16 j atoms
 };
 struct LConv2Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OC = 64, NJ = 512, SB = 1,
-                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40; // wave: all 4 oc atoms x 4 of the 32 j atoms
+                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40, PF2 = 0; // wave: all 4 oc atoms x 4 of the 32 j atoms
 };
 struct LConv3Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OC = 64, NJ = 576, SB = 3,
-                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
+                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80, PF2 = 0; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
 };
 
 struct WgradParams {
@@ -563,43 +563,50 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
 
   const long nunits = P.ns * L::GPS; // unit = sample or half sample; dY of unit u = rows [u*PIX, (u+1)*PIX)
   const long ngroups = (nunits + L::SB - 1) / L::SB;
-  u32x4 RX[NXV], RD[NDV];
-  auto gload = [&](long grp) {
-    const long n0 = grp * L::SB;
+  // TWO register sets: the groups of the next two iterations are in flight while this one is multiplied (the kernel
+  // streams its operands: with one group ahead it sat at 3.5 TB/s = one group per memory round trip per CU)
+  struct Regs {
+    u32x4 x[NXV], d[NDV];
+  };
+  Regs R0, R1;
+  // Loads are UNCONDITIONAL (indices clamped instead of predicated, groups past the end re-read the last one): only
+  // then can hipcc count the outstanding loads and wait for ONE register set (vmcnt(N)) instead of draining both.
+  auto gload = [&](Regs &R, long grp) {
+    u32x4 (&RX)[NXV] = R.x;
+    u32x4 (&RD)[NDV] = R.d;
+    const long n0 = min(grp, ngroups - 1) * L::SB;
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
-      const int v = tid + 512 * i;
-      RX[i] = zero16();
-      if (v < XV && grp < ngroups) {
-        if constexpr (U8) {
-          const long n = n0 / L::GPS + P.map.n0;
-          const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base;
-          RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.x) + off * 4 +
-                                                  (n0 % L::GPS) * (long)L::GSTRIDE)[v];
-        } else {
-          const int s = v / (PATCH / 8);
-          if (n0 + s < nunits)
-            RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.x) + n0 * PATCH)[v];
-        }
+      const int v = min(tid + 512 * i, XV - 1);
+      if constexpr (U8) {
+        const long n = n0 / L::GPS + P.map.n0;
+        const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base;
+        RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.x) + off * 4 +
+                                                (n0 % L::GPS) * (long)L::GSTRIDE)[v];
+      } else {
+        const long u = min(n0 + v / (PATCH / 8), nunits - 1); // unit of this vector (clamped: tail group)
+        RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.x) + u * PATCH)[v % (PATCH / 8)];
       }
     }
 #pragma unroll
     for (int i = 0; i < NDV; ++i) {
-      const int v = tid + 512 * i;
-      RD[i] = zero16();
-      if (v < DV && grp < ngroups) {
-        const int s = (v / VPR) / L::PIX;
-        if (n0 + s < nunits)
-          RD[i] = reinterpret_cast<const u32x4 *>(P.dy + n0 * (long)(L::PIX * L::OC))[v];
-      }
+      const int v = min(tid + 512 * i, DV - 1);
+      const long u = min(n0 + (v / VPR) / L::PIX, nunits - 1);
+      RD[i] = reinterpret_cast<const u32x4 *>(P.dy + u * (long)(L::PIX * L::OC))[v % (L::PIX * VPR)];
     }
   };
-  auto swrite = [&](int buf) {
+  // stages group `grp` from R; units past the end (tail group, prefetch beyond the last group) are staged as zeros
+  auto swrite = [&](Regs &R, int buf, long grp) {
+    u32x4 (&RX)[NXV] = R.x;
+    u32x4 (&RD)[NDV] = R.d;
     bf16 *dx = sbuf + (size_t)buf * BUF_ELEMS, *dd = dx + X_ELEMS;
+    const long u0 = grp * L::SB;
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
       const int v = tid + 512 * i;
       if (v < XV) {
+        if (u0 + v / (XV / L::SB) >= nunits)
+          RX[i] = zero16();
         if constexpr (U8) {
           auto pk = [](uint32_t lo, uint32_t hi) {
             return pack_u8_pair_bf16(lo, hi);
@@ -622,6 +629,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
       const int v = tid + 512 * i;
       if (v < DV) {
         const int row = v / VPR, cv = v - row * VPR;
+        if (u0 + row / L::PIX >= nunits)
+          RD[i] = zero16();
         *reinterpret_cast<u32x4 *>(dd + row * DYS + cv * 8) = RD[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { // bias gradient: running column sums of what this thread stages
@@ -636,14 +645,9 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     for (int e = tid; e < (KS * 32 - KPIX) * DYS; e += 512)
       sbuf[(size_t)b * BUF_ELEMS + X_ELEMS + KPIX * DYS + e] = (bf16)0.f;
 
-  long grp = blockIdx.x;
-  gload(grp);
-  swrite(0);
-  gload(grp + gridDim.x);
-  __syncthreads();
   typedef __attribute__((address_space(3))) bf16x4 *lds4;
-  for (int it = 0; grp < ngroups; grp += gridDim.x, ++it) {
-    const bf16 *px = sbuf + (size_t)(it & 1) * BUF_ELEMS, *pd = px + X_ELEMS;
+  auto multiply = [&](int buf) {
+    const bf16 *px = sbuf + (size_t)buf * BUF_ELEMS, *pd = px + X_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 fa[L::MI], fb[L::NI];
@@ -664,9 +668,38 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
         for (int j = 0; j < L::NI; ++j)
           Atom<bf16>::mma(fa[i], fb[j], acc[i][j]);
     }
-    swrite((it + 1) & 1);
-    gload(grp + 2 * (long)gridDim.x);
+  };
+  // iteration i multiplies LDS buffer i & 1 (group g_i), then stages group g_{i+1} from register set (i+1) & 1 and
+  // requests group g_{i+3} into that set; group g_{i+2} stays in flight in the other set.
+  const long gs = gridDim.x;
+  long grp = blockIdx.x;
+  if constexpr (L::PF2 != 0) {
+    gload(R0, grp);
+    gload(R1, grp + gs);
+    swrite(R0, 0, grp);
+    gload(R0, grp + 2 * gs);
     __syncthreads();
+    for (; grp < ngroups; grp += 2 * gs) {
+      multiply(0);
+      swrite(R1, 1, grp + gs);
+      gload(R1, grp + 3 * gs);
+      __syncthreads();
+      multiply(1); // (a group past the end was staged as zeros: adds nothing)
+      swrite(R0, 0, grp + 2 * gs);
+      gload(R0, grp + 4 * gs);
+      __syncthreads();
+    }
+  } else { // one group ahead (conv2 / conv3: a second register set would spill)
+    gload(R0, grp);
+    swrite(R0, 0, grp);
+    gload(R0, grp + gs);
+    __syncthreads();
+    for (int it = 0; grp < ngroups; grp += gs, ++it) {
+      multiply(it & 1);
+      swrite(R0, (it + 1) & 1, grp + gs);
+      gload(R0, grp + 2 * gs);
+      __syncthreads();
+    }
   }
   // ---- one slab per workgroup
   float *ow = P.slab_w + (long)blockIdx.x * L::OC * L::NJ;
