@@ -34,19 +34,19 @@ struct LConv1Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
-                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0;
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, PF2 = 0, STATIC_ATOMS = 0;
 };
 struct LConv2Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OUTC = 64, KS = 16,
-                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0;
+                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1;
 };
 struct LConv3Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
-                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32;
+                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32, PF2 = 0, STATIC_ATOMS = 0;
 };
 // acting-size variants (ns <= 256): one sample per group so that every CU gets a workgroup
 struct LConv2FwdSmall : LConv2Fwd {
@@ -61,14 +61,14 @@ struct LConv3Dgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
                        SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72, RPAD = 80, SPAD = 0,
-                       PRELOAD_GATES = 0;
+                       PRELOAD_GATES = 0, PF2 = 0;
 };
 struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
                        SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 80, RPAD = 80, SPAD = 0,
-                       PRELOAD_GATES = 0;
+                       PRELOAD_GATES = 0, PF2 = 0;
 };
 
 // LDS image of one unit: pixel (row, col) of the source at row*RP + col*CP bf16 elements, units SP apart.  The pixel
@@ -86,6 +86,14 @@ template <class L> constexpr int patch_src_width() { // source row width in pixe
 // the vector-memory queue (the previous atom's store + this atom's gate, a full memory round trip) once per atom.
 // conv2 dgrad: 90 -> 55 us at HALF the occupancy (196 VGPRs, 2 workgroups per CU).  conv3 dgrad (18 k-steps of
 // weights in registers) has no room for it: 2 samples per group measured equal, 4 spill.
+// forward descriptors opt in to the static atom loop with STATIC_ATOMS = 1 (conv2 fwd: 41 -> 37 us; conv1 fwd gains
+// nothing and loses a wave of occupancy to the unrolled loop's registers, conv3 fwd gets slower: both stay dynamic)
+template <class L> constexpr bool static_atoms() {
+  if constexpr (L::MODE == PM_FWD)
+    return L::STATIC_ATOMS != 0;
+  else
+    return false;
+}
 template <class L> constexpr bool preload_gates() {
   if constexpr (L::MODE == PM_FWD)
     return false;
@@ -108,6 +116,7 @@ struct PatchParams {
   long ns;            // samples
   SampleMap map;      // conv1 only: where sample n's packed stack lives (units: u32 pixels)
   float scale;        // fwd epilogue: v*scale + bias
+  bf16 *dummy;        // fwd: >= 8 KB scratch that lanes without an output pixel store to (see the atom loop)
 };
 
 __device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
@@ -163,33 +172,62 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
   // a "unit" is a sample (GPS == 1) or a half sample (conv1); a group is SB consecutive units
   const long nunits = P.ns * L::GPS;
   const long ngroups = (nunits + L::SB - 1) / L::SB;
-  u32x4 R[NV];
-  auto gload = [&](long grp) {
-    const long n0 = grp * L::SB;
+  // Prefetch registers.  Loads are UNCONDITIONAL (vector index and group clamped, units past the end zeroed when they
+  // are staged): a predicated load may be skipped by a whole wave, and then hipcc cannot count the outstanding
+  // vector-memory operations and drains them all (vmcnt(0)) at the next use.
+  struct Regs {
+    u32x4 r[NV];
+  };
+  Regs R0, R1;
+  auto gload = [&](Regs &RR, long grp) {
+    u32x4 (&R)[NV] = RR.r;
+    if constexpr (static_atoms<L>()) {
+      const long n0 = min(grp, ngroups - 1) * L::SB;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int v = tid + NT * i;
-      R[i] = zero16();
-      if (v < SRC_VECS && grp < ngroups) {
+      for (int i = 0; i < NV; ++i) {
+        const int v = min(tid + NT * i, SRC_VECS - 1);
         if constexpr (U8) { // SB == 1: one half of a packed stack per group, located through the slot map
           const long n = n0 / L::GPS + P.map.n0;
           const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base; // u32 pixels
           R[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.in) + off * 4 +
                                                  (n0 % L::GPS) * (long)L::GSTRIDE)[v];
         } else {
-          const int s = v / (PATCH / 8);
-          if (n0 + s < nunits)
-            R[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.in) + n0 * PATCH)[v];
+          const long u = min(n0 + v / (PATCH / 8), nunits - 1);
+          R[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.in) + u * PATCH)[v % (PATCH / 8)];
+        }
+      }
+    } else { // predicated loads (the kernels whose atom loop is dynamic drain the queue at the staging write anyway)
+      const long n0 = grp * L::SB;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + NT * i;
+        R[i] = zero16();
+        if (v < SRC_VECS && grp < ngroups) {
+          if constexpr (U8) {
+            const long n = n0 / L::GPS + P.map.n0;
+            const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base; // u32 pixels
+            R[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.in) + off * 4 +
+                                                   (n0 % L::GPS) * (long)L::GSTRIDE)[v];
+          } else {
+            const int s = v / (PATCH / 8);
+            if (n0 + s < nunits)
+              R[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.in) + n0 * PATCH)[v];
+          }
         }
       }
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](Regs &RR, int buf, long grp) {
+    u32x4 (&R)[NV] = RR.r;
     bf16 *dst = sbuf + (size_t)buf * BUF_ELEMS;
+    const long u0 = grp * L::SB;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + NT * i;
       if (v < SRC_VECS) {
+        if constexpr (static_atoms<L>())
+          if (u0 + v / (SRC_VECS / L::SB) >= nunits) // unit past the end: stage zeros
+            R[i] = zero16();
         if constexpr (U8) { // 16 bytes -> 16 bf16 (exact), two LDS vectors
           auto pk = [](uint32_t lo, uint32_t hi) {
             return pack_u8_pair_bf16(lo, hi);
@@ -216,15 +254,11 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
     }
   };
 
-  long grp = blockIdx.x;
-  gload(grp);
-  swrite(0);
-  gload(grp + gridDim.x);
-  __syncthreads();
-  for (int it = 0; grp < ngroups; grp += gridDim.x, ++it) {
-    const bf16 *pb = sbuf + (size_t)(it & 1) * BUF_ELEMS;
+  constexpr bool STATIC = static_atoms<L>(); // static atom count + unconditional stores (see process())
+  auto process = [&](int bufi, long grp) {
+    const bf16 *pb = sbuf + (size_t)bufi * BUF_ELEMS;
     const long n0 = grp * L::SB; // first unit of this group; unit u covers output pixels [u*PIX, (u+1)*PIX)
-    const int count = (int)min((long)L::SB, nunits - n0);
+    const int count = (int)max(0L, min((long)L::SB, nunits - n0));
     constexpr int APW = (NATOM + NL - 1) / NL; // atoms per wave and group
     constexpr bool PRE = L::MODE != PM_FWD && preload_gates<L>();
     u32x4 gates[PRE ? APW : 1];
@@ -246,7 +280,7 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
     }
     auto atom_body = [&](int atom, u32x4 gate_pre) {
       const int q = atom * 16 + fr;
-      const bool qok = q < count * L::PIX;
+      const bool qok = atom < NATOM && q < count * L::PIX;
       const int s = min(q / L::PIX, L::SB - 1), p = q - (q / L::PIX) * L::PIX;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       long out_off;
@@ -297,17 +331,25 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
           Atom<bf16>::mma(W[1][ks], b, acc1);
         }
       }
-      if (qok) {
-        if constexpr (L::MODE == PM_FWD) {
-          float v0[4], v1[4];
+      if constexpr (L::MODE == PM_FWD) {
+        // EVERY lane stores (lanes without a pixel to the scratch `dummy`), and every wave runs the same number of
+        // atoms: the vector-memory operations per group are then a compile-time constant, hipcc waits for the
+        // prefetched registers with a COUNTED vmcnt and these stores are never drained inside the loop.
+        float v0[4], v1[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v0[r] = fmaxf(acc0[r] * P.scale + bias_r[0][r], 0.f);
-            v1[r] = fmaxf(acc1[r] * P.scale + bias_r[1][r], 0.f);
-          }
-          const u32x2 lo = pack4_bf16(v0[0], v0[1], v0[2], v0[3]), hi = pack4_bf16(v1[0], v1[1], v1[2], v1[3]);
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = fmaxf(acc0[r] * P.scale + bias_r[0][r], 0.f);
+          v1[r] = fmaxf(acc1[r] * P.scale + bias_r[1][r], 0.f);
+        }
+        const u32x2 lo = pack4_bf16(v0[0], v0[1], v0[2], v0[3]), hi = pack4_bf16(v1[0], v1[1], v1[2], v1[3]);
+        if constexpr (STATIC) {
+          bf16 *dstp = qok ? P.out + out_off : P.dummy + tid * 8;
+          *reinterpret_cast<u32x4 *>(dstp) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else if (qok) {
           *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        } else {
+        }
+      } else if (qok) {
+        {
           auto gated = [](uint32_t w, int h, float v) { // ReLU gate on the stored bf16 activation
             const float a = bf16_bits_to_f32(h ? (w >> 16) : (w & 0xFFFFu));
             return a > 0.f ? v : 0.f;
@@ -325,13 +367,45 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
       for (int ak = 0; ak < APW; ++ak)
         if (pl + ak * NL < NATOM)
           atom_body(pl + ak * NL, gates[ak]);
+    } else if constexpr (STATIC) {
+#pragma unroll
+      for (int ak = 0; ak < APW; ++ak)
+        atom_body(pl + ak * NL, zero16());
     } else {
       for (int atom = pl; atom < NATOM; atom += NL)
         atom_body(atom, zero16());
     }
-    swrite((it + 1) & 1);
-    gload(grp + 2 * (long)gridDim.x);
+  };
+
+  const long gs = gridDim.x;
+  long grp = blockIdx.x;
+  if constexpr (STATIC && L::PF2 != 0) { // two register sets: the groups of the next two iterations are in flight
+    gload(R0, grp);
+    gload(R1, grp + gs);
+    swrite(R0, 0, grp);
+    gload(R0, grp + 2 * gs);
     __syncthreads();
+    for (; grp < ngroups; grp += 2 * gs) {
+      process(0, grp);
+      swrite(R1, 1, grp + gs);
+      gload(R1, grp + 3 * gs);
+      __syncthreads();
+      process(1, grp + gs); // (a group past the end: no lane has a pixel, everything goes to the scratch)
+      swrite(R0, 0, grp + 2 * gs);
+      gload(R0, grp + 4 * gs);
+      __syncthreads();
+    }
+  } else {
+    gload(R0, grp);
+    swrite(R0, 0, grp);
+    gload(R0, grp + gs);
+    __syncthreads();
+    for (int it = 0; grp < ngroups; grp += gs, ++it) {
+      process(it & 1, grp);
+      swrite(R0, (it + 1) & 1, grp + gs);
+      gload(R0, grp + 2 * gs);
+      __syncthreads();
+    }
   }
 }
 

@@ -34,6 +34,17 @@ template <class K> static void allow_smem(K kernel, size_t bytes) {
                             (int)bytes);
 }
 
+// scratch that forward lanes without an output pixel store to (keeps the store count per group static)
+static bf16 *fwd_dummy() {
+  static bf16 *p[16] = {nullptr};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  if (!p[dev] && hipMalloc(reinterpret_cast<void **>(&p[dev]), 16 * 1024) != hipSuccess)
+    p[dev] = nullptr; // (a null scratch would fault: allocation failure is reported by the next HIP call)
+  return p[dev];
+}
+
 // NW waves per workgroup, WPC persistent workgroups per CU
 template <class L, int NW, int WPC> static void launch_patch(hipStream_t s, const PatchParams &P) {
   static bool once = false;
@@ -50,12 +61,12 @@ template <class L, int NW, int WPC> static void launch_patch(hipStream_t s, cons
 
 void patch_conv1_fwd(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
                      long ns) {
-  PatchParams P{obs, static_cast<const bf16 *>(W1), b1, nullptr, static_cast<bf16 *>(a1), ns, map, 1.0f / 255.0f};
+  PatchParams P{obs, static_cast<const bf16 *>(W1), b1, nullptr, static_cast<bf16 *>(a1), ns, map, 1.0f / 255.0f, fwd_dummy()};
   launch_patch<LConv1Fwd, 8, 2>(s, P);
 }
 void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns) {
   PatchParams P{a1, static_cast<const bf16 *>(W2), b2, nullptr, static_cast<bf16 *>(a2), ns, SampleMap{1, 0, 0, 0, 0},
-                1.0f};
+                1.0f, fwd_dummy()};
   if (ns <= 256)
     launch_patch<LConv2FwdSmall, 8, 1>(s, P);
   else
@@ -63,7 +74,7 @@ void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float 
 }
 void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns) {
   PatchParams P{a2, static_cast<const bf16 *>(W3), b3, nullptr, static_cast<bf16 *>(a3), ns, SampleMap{1, 0, 0, 0, 0},
-                1.0f};
+                1.0f, fwd_dummy()};
   if (ns <= 256)
     launch_patch<LConv3FwdSmall, 8, 1>(s, P);
   else
@@ -71,12 +82,12 @@ void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float 
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),
-                ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
+                ns,  SampleMap{1, 0, 0, 0, 0},       1.0f, nullptr};
   launch_patch<LConv3Dgrad, 8, 1>(s, P); // the 4-wave / 2-per-CU variant measured slower here (56 vs 48 us)
 }
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {
   PatchParams P{dz2, static_cast<const bf16 *>(W2d), nullptr, static_cast<const bf16 *>(a1), static_cast<bf16 *>(dz1),
-                ns,  SampleMap{1, 0, 0, 0, 0},       1.0f};
+                ns,  SampleMap{1, 0, 0, 0, 0},       1.0f, nullptr};
   launch_patch<LConv2DgradW4, 4, 2>(s, P); // 2 per CU: the preloaded gates take the kernel to 196 VGPRs
 }
 
