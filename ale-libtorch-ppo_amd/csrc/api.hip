@@ -275,6 +275,8 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(hipEventCreateWithFlags(&c->ev_comm0, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_comm1, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_tmp, hipEventDisableTiming));
+  for (hipEvent_t *e : {&c->ev_head, &c->ev_dz3, &c->ev_dz2, &c->ev_wg})
+    CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_adam, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
   CK(dalloc(&c->obs, (size_t)E * (T + 1) * FRAME_PIX * 4));
@@ -377,7 +379,8 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
       hipEventDestroy(pc.start[i]);
       hipEventDestroy(pc.stop[i]);
     }
-  for (hipEvent_t e : {c->ev_bucket0, c->ev_comm0, c->ev_comm1, c->ev_tmp, c->ev_adam, c->ev_pack})
+  for (hipEvent_t e : {c->ev_bucket0, c->ev_comm0, c->ev_comm1, c->ev_tmp, c->ev_adam, c->ev_pack, c->ev_head, c->ev_dz3,
+                       c->ev_dz2, c->ev_wg})
     if (e)
       hipEventDestroy(e);
   if (c->stream)
@@ -758,6 +761,21 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   const int nblk_head = (int)std::min<long>(MAXS_HEAD, (B + 15) / 16);
   const int nblk_sq = (int)std::min<size_t>(1024, (L.total() + 4095) / 4096);
 
+  // One GPU, not profiling: the three weight-gradient kernels run on the side stream next to the dgrad chain
+  // (fc wgrad || fc dgrad, conv3 wgrad || conv3 dgrad, conv2 wgrad || conv2 dgrad -> conv1 wgrad).  Every kernel is a
+  // full-GPU persistent grid, so this mostly fills the drain / ramp bubbles between dependent launches.
+  static const bool two_env = [] {
+    const char *e = std::getenv("ALEPPO_BWD_STREAMS");
+    return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing)
+  }();
+  const bool two = two_env && !dp && !c->prof_on;
+  hipStream_t sw = two ? c->comm_stream : s; // stream of the weight-gradient kernels
+  auto fork = [&](hipEvent_t ev) { // sw continues after everything enqueued on s so far
+    if (two) {
+      (void)hipEventRecord(ev, s);
+      (void)hipStreamWaitEvent(sw, ev, 0);
+    }
+  };
   bool pack_pending = false;
   for (int ep = 0; ep < epochs; ++ep)
     for (int mb = 0; mb < M; ++mb) { // contiguous env-major slices; randperm unused (Q1)
@@ -778,13 +796,14 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
         pack_pending = false;
       }
+      fork(c->ev_head); // dh is ready
       prof_begin(c, ALEPPO_K_FC_DGRAD);
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
       prof_end(c, ALEPPO_K_FC_DGRAD);
       prof_begin(c, ALEPPO_K_FC_WGRAD);
       // split-K slabs (or, with one slice, straight into the gradient tensor)
       const bool fc_direct = !wg_pipe && fc_wgrad_slices(prec, B) == 1;
-      const int Sfc = fc_wgrad(s, prec, c->dh, c->a3, fc_direct ? c->G + L.off[P_WFC] : sWfc,
+      const int Sfc = fc_wgrad(sw, prec, c->dh, c->a3, fc_direct ? c->G + L.off[P_WFC] : sWfc,
                                fc_direct ? c->G + L.off[P_BFC] : sBfc, B, H);
       prof_end(c, ALEPPO_K_FC_WGRAD);
       // bucket 0 = heads + fc.  With data parallelism it is reduced now so that its all-reduce overlaps the conv
@@ -805,21 +824,27 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         NCCLCHK(c, ncclAllReduce(c->G, c->G, L.bucket0_end, ncclFloat, ncclSum, comm, c->comm_stream));
         HIPCHK(c, hipEventRecord(c->ev_comm0, c->comm_stream));
       }
+      fork(c->ev_dz3); // dz3 is ready
       prof_begin(c, ALEPPO_K_CONV3_DGRAD);
       conv3_dgrad(s, prec, c->dz3, c->W3d, c->a2, c->dz2, B);
       prof_end(c, ALEPPO_K_CONV3_DGRAD);
       prof_begin(c, ALEPPO_K_CONV3_WGRAD);
-      const int S3 = conv3_wgrad(s, prec, c->dz3, c->a2, sW3, sB3, B);
+      const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
       prof_end(c, ALEPPO_K_CONV3_WGRAD);
+      fork(c->ev_dz2); // dz2 is ready
       prof_begin(c, ALEPPO_K_CONV2_DGRAD);
       conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
       prof_end(c, ALEPPO_K_CONV2_DGRAD);
       prof_begin(c, ALEPPO_K_CONV2_WGRAD);
-      const int S2 = conv2_wgrad(s, prec, c->dz2, c->a1, sW2, sB2, B);
+      const int S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
       prof_end(c, ALEPPO_K_CONV2_WGRAD);
       prof_begin(c, ALEPPO_K_CONV1_WGRAD);
       const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
       prof_end(c, ALEPPO_K_CONV1_WGRAD);
+      if (two) { // join: the slab reduce below reads every weight-gradient slab
+        HIPCHK(c, hipEventRecord(c->ev_wg, sw));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_wg, 0));
+      }
       prof_begin(c, ALEPPO_K_REDUCE);
       {
         ReduceSeg segs[10] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
