@@ -271,6 +271,7 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&c->wg_stream, hipStreamNonBlocking));
   CK(hipEventCreateWithFlags(&c->ev_bucket0, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_comm0, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_comm1, hipEventDisableTiming));
@@ -387,6 +388,8 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
     hipStreamDestroy(c->stream);
   if (c->comm_stream)
     hipStreamDestroy(c->comm_stream);
+  if (c->wg_stream)
+    hipStreamDestroy(c->wg_stream);
   delete c;
 }
 
@@ -761,15 +764,16 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   const int nblk_head = (int)std::min<long>(MAXS_HEAD, (B + 15) / 16);
   const int nblk_sq = (int)std::min<size_t>(1024, (L.total() + 4095) / 4096);
 
-  // One GPU, not profiling: the three weight-gradient kernels run on the side stream next to the dgrad chain
-  // (fc wgrad || fc dgrad, conv3 wgrad || conv3 dgrad, conv2 wgrad || conv2 dgrad -> conv1 wgrad).  Every kernel is a
-  // full-GPU persistent grid, so this mostly fills the drain / ramp bubbles between dependent launches.
+  // Unless profiling, the three weight-gradient kernels (and the slab reduce of bucket 0) run on their own stream
+  // next to the dgrad chain (fc wgrad || fc dgrad, conv3 wgrad || conv3 dgrad, conv2 wgrad || conv2 dgrad -> conv1
+  // wgrad).  Every kernel is a latency-bound full-GPU persistent grid: co-scheduling fills the drain / ramp bubbles
+  // between dependent launches.
   static const bool two_env = [] {
     const char *e = std::getenv("ALEPPO_BWD_STREAMS");
-    return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing)
+    return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
-  const bool two = two_env && !dp && !c->prof_on;
-  hipStream_t sw = two ? c->comm_stream : s; // stream of the weight-gradient kernels
+  const bool two = two_env && !c->prof_on;
+  hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
   auto fork = [&](hipEvent_t ev) { // sw continues after everything enqueued on s so far
     if (two) {
       (void)hipEventRecord(ev, s);
@@ -813,13 +817,16 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
                                   {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
                                   {sBfc, wg_pipe ? nblk_head : Sfc, (long)H, (long)L.off[P_BFC]}};
       const int nseg0 = fc_direct ? 2 : 4;
-      if (dp) {
+      // bucket 0 is reduced early only for the all-reduce overlap: on one GPU an early reduce next to the conv dgrads
+      // measured slower (8.60 vs 8.38 ms per update) than one reduce of all ten slab groups at the end
+      const bool early0 = dp;
+      if (early0) {
         prof_begin(c, ALEPPO_K_REDUCE);
-        launch_reduce_slabs(s, segs0, nseg0, c->G);
+        launch_reduce_slabs(sw, segs0, nseg0, c->G);
         prof_end(c, ALEPPO_K_REDUCE);
       }
       if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs
-        HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
+        HIPCHK(c, hipEventRecord(c->ev_bucket0, sw));
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
         NCCLCHK(c, ncclAllReduce(c->G, c->G, L.bucket0_end, ncclFloat, ncclSum, comm, c->comm_stream));
         HIPCHK(c, hipEventRecord(c->ev_comm0, c->comm_stream));
@@ -851,7 +858,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
                               {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]},
                               {sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
         int nseg = 6;
-        if (!dp)
+        if (!early0)
           for (int i = 0; i < nseg0; ++i)
             segs[nseg++] = segs0[i];
         launch_reduce_slabs(s, segs, nseg, c->G);

@@ -62,7 +62,7 @@ struct Ctx {
   long batch_n = 0;    // samples currently in the training arrays
   ParamLayout L;
   std::string err;
-  hipStream_t stream = nullptr, comm_stream = nullptr;
+  hipStream_t stream = nullptr, comm_stream = nullptr, wg_stream = nullptr;
   hipEvent_t ev_bucket0 = nullptr, ev_comm0 = nullptr, ev_comm1 = nullptr, ev_tmp = nullptr;
   hipEvent_t ev_head = nullptr, ev_dz3 = nullptr, ev_dz2 = nullptr, ev_wg = nullptr; // dgrad chain -> wgrad side stream
   hipEvent_t ev_adam = nullptr, ev_pack = nullptr; // adam done -> dgrad weight repack on the side stream -> done
