@@ -845,24 +845,32 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_begin(c, ALEPPO_K_CONV2_WGRAD);
       const int S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
       prof_end(c, ALEPPO_K_CONV2_WGRAD);
+      // conv1 wgrad is the last link of the dgrad chain and runs alone on s: meanwhile the wgrad stream reduces every
+      // slab group that is already complete (conv3, conv2 and - on one GPU - heads + fc); only conv1's slabs are left
+      // for the reduce after the join.
+      ReduceSeg segs[10] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
+                            {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]}};
+      int nseg = 4;
+      if (!early0)
+        for (int i = 0; i < nseg0; ++i)
+          segs[nseg++] = segs0[i];
+      if (two) {
+        prof_begin(c, ALEPPO_K_REDUCE);
+        launch_reduce_slabs(sw, segs, nseg, c->G);
+        prof_end(c, ALEPPO_K_REDUCE);
+        nseg = 0;
+      }
       prof_begin(c, ALEPPO_K_CONV1_WGRAD);
       const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
       prof_end(c, ALEPPO_K_CONV1_WGRAD);
-      if (two) { // join: the slab reduce below reads every weight-gradient slab
+      if (two) { // join: sumsq / Adam read the whole gradient
         HIPCHK(c, hipEventRecord(c->ev_wg, sw));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_wg, 0));
       }
       prof_begin(c, ALEPPO_K_REDUCE);
-      {
-        ReduceSeg segs[10] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
-                              {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]},
-                              {sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
-        int nseg = 6;
-        if (!early0)
-          for (int i = 0; i < nseg0; ++i)
-            segs[nseg++] = segs0[i];
-        launch_reduce_slabs(s, segs, nseg, c->G);
-      }
+      segs[nseg++] = ReduceSeg{sW1, S1, 32 * 256, (long)L.off[P_W1]};
+      segs[nseg++] = ReduceSeg{sB1, S1, 32, (long)L.off[P_B1]};
+      launch_reduce_slabs(s, segs, nseg, c->G);
       prof_end(c, ALEPPO_K_REDUCE);
       if (dp) {
         HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
