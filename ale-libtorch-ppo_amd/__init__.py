@@ -48,7 +48,7 @@ EXPORTS = [
     "aleppo_comm_init", "aleppo_gae", "aleppo_vision_resize_area", "aleppo_vision_rgb_to_gray", "aleppo_preprocess",
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
     "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option", "aleppo_export_optimizer",
-    "aleppo_import_optimizer",
+    "aleppo_import_optimizer", "aleppo_replay_rollout",
 ]
 
 
@@ -327,6 +327,15 @@ class Engine:
         rc = self._f_step(self._ctx, frames_addr, kind, location, rewards_addr, term_addr, trunc_addr, start_addr)
         if rc:
             self._c(rc)
+
+    def replay_rollout(self, frames_addr, kind, slot_stride_bytes, rewards, terminated, truncated, episode_start):
+        """aleppo_replay_rollout: the T-slot act/step loop over a recorded trace (device frames, host [T][E] scalars)"""
+        r, te, tr, st = _f32(rewards), _u8(terminated), _u8(truncated), _u8(episode_start)
+        for a in (r, te, tr, st):
+            if a.shape != (self.T, self.E):
+                raise AleppoInvalidArgument("replay_rollout: scalars must be [T][E]")
+        self._c(lib().aleppo_replay_rollout(self._ctx, C.c_void_p(frames_addr), int(kind),
+                                            C.c_size_t(slot_stride_bytes), _ptr(r), _ptr(te), _ptr(tr), _ptr(st)))
 
     def set_gray_lut(self, lut):
         self._c(lib().aleppo_set_gray_lut(self._ctx, _ptr(_u8(lut))))

@@ -655,6 +655,26 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
   c->t++;
   return ALEPPO_OK;
 }
+extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int kind, size_t slot_stride_bytes,
+                                     const float *rewards, const uint8_t *terminated, const uint8_t *truncated,
+                                     const uint8_t *episode_start) {
+  CHECK_CTX(c);
+  if (!frames || !rewards || !terminated || !truncated || !episode_start)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (c->t != 0)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "replay_rollout needs an empty rollout buffer");
+  const size_t E = (size_t)c->E;
+  for (int t = 0; t < c->T; ++t) { // rollout.cc:198-278 with the emulator replaced by the recorded trace
+    int rc = aleppo_act(c, nullptr, nullptr);
+    if (rc)
+      return rc;
+    rc = aleppo_step(c, frames + (size_t)t * slot_stride_bytes, kind, ALEPPO_DEVICE, rewards + (size_t)t * E,
+                     terminated + (size_t)t * E, truncated + (size_t)t * E, episode_start + (size_t)t * E);
+    if (rc)
+      return rc;
+  }
+  return ALEPPO_OK;
+}
 extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
   CHECK_CTX(c);
   if (!lut256)

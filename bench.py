@@ -119,11 +119,14 @@ def run(args):
         rew, te, tr, st = plans[plan_i]
         plan_i += 1
         t0 = time.perf_counter()
-        ra, ta, ua, sa = rew.ctypes.data, te.ctypes.data, tr.ctypes.data, st.ctypes.data
-        for t in range(T):
-            eng.act_fast()  # forward + sample; actions land in pinned host memory (an emulator reads them here)
-            eng.step_ptr(base_ptr + t * slot_bytes, pkg.DEVICE, pkg.FRAMES_RAW_PAIR, ra + 4 * E * t, ta + E * t,
-                         ua + E * t, sa + E * t)
+        if args.python_slot_loop:  # the same T-slot loop driven from Python (ctypes call overhead on every slot)
+            ra, ta, ua, sa = rew.ctypes.data, te.ctypes.data, tr.ctypes.data, st.ctypes.data
+            for t in range(T):
+                eng.act_fast()  # forward + sample; actions land in pinned host memory (an emulator reads them here)
+                eng.step_ptr(base_ptr + t * slot_bytes, pkg.DEVICE, pkg.FRAMES_RAW_PAIR, ra + 4 * E * t, ta + E * t,
+                             ua + E * t, sa + E * t)
+        else:  # native host loop (the reference's Rollout::rollout is C++): act -> actions to pinned host -> step
+            eng.replay_rollout(base_ptr, pkg.FRAMES_RAW_PAIR, slot_bytes, rew, te, tr, st)
         t1 = time.perf_counter()
         eng.finish_rollout()
         t2 = time.perf_counter()
@@ -355,5 +358,7 @@ if __name__ == "__main__":
     ap.add_argument("--minibatches", type=int, default=4)
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--python-slot-loop", action="store_true",
+                    help="drive the per-slot act/step loop from Python instead of aleppo_replay_rollout")
     ap.add_argument("--no-v1", action="store_true", help="skip the secondary v1.yaml-shape leg")
     run(ap.parse_args())

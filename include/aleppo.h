@@ -159,6 +159,16 @@ int aleppo_record_step(aleppo_ctx *ctx, const float *rewards, const uint8_t *ter
 int aleppo_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int location, const float *rewards,
                 const uint8_t *terminated, const uint8_t *truncated, const uint8_t *episode_start);
 
+/* Rollout::rollout()'s slot loop (rollout.cc:198-278) over a PRE-RECORDED environment trace: for t in [0, T):
+ * aleppo_act (built-in RNG) then aleppo_step with slot t of the trace.  frames: DEVICE memory, slot t at
+ * frames + t * slot_stride_bytes (16-byte aligned); rewards [T][E] f32 and terminated / truncated / episode_start
+ * [T][E] u8 are HOST arrays.  The sampled actions do not influence a recorded trace, so this entry point only
+ * serves replay / throughput measurement with the whole host loop native (like the reference's C++ loop); a live
+ * emulator calls aleppo_act / aleppo_step itself.  Leaves the context ready for aleppo_finish_rollout. */
+int aleppo_replay_rollout(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, size_t slot_stride_bytes,
+                          const float *rewards, const uint8_t *terminated, const uint8_t *truncated,
+                          const uint8_t *episode_start);
+
 /* Tail of Rollout::rollout (rollout.cc:268-270) + Buffer::get (buffer.cc:58-77) + prepare_batch
  * (train.cc:272-283): bootstrap forward (draws and discards one sample like the reference), reward
  * clamp, GAE, returns, masks, old log-probs.  ALEPPO_ERR_RUNTIME if the buffer is not full

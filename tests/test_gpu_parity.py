@@ -319,6 +319,44 @@ def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M):
         np.testing.assert_allclose(m1["grad_norm"], w["grad_norm"], rtol=5e-2)
 
 
+def test_replay_rollout_equals_the_manual_slot_loop(pkg):
+    """aleppo_replay_rollout (the native T-slot act/step loop over a recorded trace) leaves exactly the rollout the
+    per-slot calls leave: same built-in RNG stream, same observations, scalars, actions and values"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # device memory for the recorded frames (no torch in the test process)
+    E, T, A, H = 8, 6, 4, 64
+    params = hf.fill_params(1010, H, A)
+    frames = np.ascontiguousarray(hf.hf_bytes(1011, (T, E, 84, 84)))
+    dptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(frames.nbytes)) == 0
+    assert hip.hipMemcpy(dptr, frames.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(frames.nbytes), 1) == 0
+    base = dptr.value
+    rew = hf.hf_range(1012, (T, E), -2, 2)
+    term = (hf.hf_unit(1013, T * E) < np.float32(0.1)).astype(np.uint8).reshape(T, E)
+    trunc = np.zeros((T, E), np.uint8)
+    start = (hf.hf_unit(1014, T * E) < np.float32(0.1)).astype(np.uint8).reshape(T, E)
+    start[0, :] = 1
+    term[start != 0] = 0  # flags are mutually exclusive (gae.cc:52-56)
+    got = []
+    for native in (False, True):
+        eng = pkg.Engine(E, T, A, H, precision=pkg.FP32, seed=77)
+        eng.load_params(params)
+        if native:
+            eng.replay_rollout(base, pkg.FRAMES_84, E * 84 * 84, rew, term, trunc, start)
+        else:
+            for t in range(T):
+                eng.act_fast()
+                eng.step_ptr(base + t * E * 84 * 84, pkg.DEVICE, pkg.FRAMES_84, rew[t].ctypes.data,
+                             term[t].ctypes.data, trunc[t].ctypes.data, start[t].ctypes.data)
+        eng.finish_rollout()
+        got.append({k: eng.read_batch(k) for k in ("observations", "actions", "advantages", "returns", "masks",
+                                                   "log_probs", "values", "rewards")})
+        eng.close()
+    hip.hipFree(dptr)
+    for k in got[0]:
+        np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=k)
+
+
 # ------------------------------------------------------------------ the whole rollout protocol
 def _run_rollouts(pkg, E, T, A, H, rollouts, kind):
     params = hf.fill_params(610, H, A)
