@@ -481,38 +481,30 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   ActW<LConv1Full> W1;
   ActW<LConv2FwdSmall> W2;
   ActW<LConv3FwdSmall> W3;
-  bool have_w = false;
-  for (long n = blockIdx.x; n < P.ns; n += gridDim.x) {
-    { // stage + widen the packed u8 stack: 1764 16-byte vectors
-      const long nn = n + P.map.n0;
-      const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base;
-      const u32x4 *src = reinterpret_cast<const u32x4 *>(P.obs + off);
-      auto pk = [](uint32_t lo, uint32_t hi) {
-        return pack_u8_pair_bf16(lo, hi);
-      };
-      u32x4 R[4];
+  u32x4 R[4];
+  // packed u8 stack of sample n: 1764 16-byte vectors.  UNCONDITIONAL loads (index clamped): hipcc can then count
+  // them and wait for these four alone while the 42 weight loads issued behind them stay in flight (with a
+  // predicated load it drained the whole queue - all three layers' weights - before widening the observation).
+  auto load_obs = [&](long n) {
+    const long nn = n + P.map.n0;
+    const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base;
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(P.obs + off);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int v = tid + 512 * i;
-        R[i] = v < 1764 ? src[v] : zero16();
-      }
-      if (!have_w) { // all three layers' weights: issued behind the observation loads, consumed much later
-        W1.load(P.w1, P.b1, wave, lane);
-        W2.load(P.w2, P.b2, wave, lane);
-        W3.load(P.w3, P.b3, wave, lane);
-        have_w = true;
-      }
+    for (int i = 0; i < 4; ++i)
+      R[i] = src[min(tid + 512 * i, 1763)];
+  };
+  auto sample = [&](long n) { // widen the staged stack, then conv1 -> conv2 -> conv3 out of LDS
+    auto pk = [](uint32_t lo, uint32_t hi) { return pack_u8_pair_bf16(lo, hi); };
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int v = tid + 512 * i;
-        if (v < 1764) {
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + 512 * i;
+      if (v < 1764) {
 #pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const uint32_t w0 = R[i][2 * d], w1 = R[i][2 * d + 1];
-            reinterpret_cast<u32x4 *>(sx)[2 * v + d] =
-                u32x4{pk(w0 & 255u, (w0 >> 8) & 255u), pk((w0 >> 16) & 255u, w0 >> 24),
-                      pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
-          }
+        for (int d = 0; d < 2; ++d) {
+          const uint32_t w0 = R[i][2 * d], w1 = R[i][2 * d + 1];
+          reinterpret_cast<u32x4 *>(sx)[2 * v + d] =
+              u32x4{pk(w0 & 255u, (w0 >> 8) & 255u), pk((w0 >> 16) & 255u, w0 >> 24),
+                    pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
         }
       }
     }
@@ -533,6 +525,18 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
     act_phase<LConv3FwdSmall>(s2, W3, 1.0f, wave, lane,
                               [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(out + q * 64 + oc) = v; });
     __syncthreads();
+  };
+  long n = blockIdx.x;
+  if (n >= P.ns)
+    return;
+  load_obs(n);
+  W1.load(P.w1, P.b1, wave, lane); // all three layers' weights: issued behind the observation loads, consumed later
+  W2.load(P.w2, P.b2, wave, lane);
+  W3.load(P.w3, P.b3, wave, lane);
+  sample(n);
+  for (n += gridDim.x; n < P.ns; n += gridDim.x) {
+    load_obs(n);
+    sample(n);
   }
 }
 
