@@ -34,7 +34,7 @@ struct LConv1Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
-                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, PF2 = 0, STATIC_ATOMS = 0;
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1;
 };
 struct LConv2Fwd {
   static constexpr int MODE = PM_FWD;
@@ -86,8 +86,8 @@ template <class L> constexpr int patch_src_width() { // source row width in pixe
 // the vector-memory queue (the previous atom's store + this atom's gate, a full memory round trip) once per atom.
 // conv2 dgrad: 90 -> 55 us at HALF the occupancy (196 VGPRs, 2 workgroups per CU).  conv3 dgrad (18 k-steps of
 // weights in registers) has no room for it: 2 samples per group measured equal, 4 spill.
-// forward descriptors opt in to the static atom loop with STATIC_ATOMS = 1 (conv2 fwd: 41 -> 37 us; conv1 fwd gains
-// nothing and loses a wave of occupancy to the unrolled loop's registers, conv3 fwd gets slower: both stay dynamic)
+// forward descriptors opt in to the static atom loop with STATIC_ATOMS = 1 (conv2 fwd: 41 -> 37 us, conv1 fwd: 61 ->
+// 55 us with ONE register set - a second set costs it a wave of occupancy; conv3 fwd gets slower and stays dynamic)
 template <class L> constexpr bool static_atoms() {
   if constexpr (L::MODE == PM_FWD)
     return L::STATIC_ATOMS != 0;
