@@ -79,8 +79,12 @@ template <int MODE, int NST> static void launch_pipe(hipStream_t s, const PipePa
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     once = true;
   }
-  // one persistent workgroup per CU (a multiple of 8 so the XCD-grouped job maps apply); jobless workgroups exit at once
-  const int grid = P.njobs >= pipe_cus() / 4 ? pipe_cus() / 8 * 8 : std::min(P.njobs, pipe_cus());
+  // Persistent workgroups, at most one per CU: every workgroup gets the SAME number of jobs (800 dgrad jobs run as
+  // 200 workgroups x 4 rather than 256 workgroups of which 32 do a 4th round), which takes the same time and leaves the
+  // other CUs to the weight-gradient kernel co-scheduled on the second stream.  A multiple of 8 so that the
+  // XCD-grouped job maps apply; jobless workgroups exit at once.
+  const int cus = pipe_cus() / 8 * 8, rounds = (P.njobs + cus - 1) / cus;
+  const int grid = P.njobs >= cus / 4 ? std::min(cus, ((P.njobs + rounds - 1) / rounds + 7) / 8 * 8) : std::min(P.njobs, cus);
   hipLaunchKernelGGL((gemm_pipe_kernel<MODE, NST>), dim3(grid), dim3(512), sm, s, P);
 }
 static bool use_pipe() { return tune("ALEPPO_FC_PIPE", 1) != 0; }
