@@ -34,19 +34,19 @@ struct LConv1Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
-                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1;
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1, ONE_ATOM = 0;
 };
 struct LConv2Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OUTC = 64, KS = 16,
-                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1;
+                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1, ONE_ATOM = 0;
 };
 struct LConv3Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
-                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32, PF2 = 0, STATIC_ATOMS = 0;
+                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32, PF2 = 0, STATIC_ATOMS = 0, ONE_ATOM = 0;
 };
 // acting-size variants (ns <= 256): one sample per group so that every CU gets a workgroup
 struct LConv2FwdSmall : LConv2Fwd {
@@ -61,14 +61,14 @@ struct LConv3Dgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
                        SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72, RPAD = 80, SPAD = 0,
-                       PRELOAD_GATES = 0, PF2 = 0;
+                       PRELOAD_GATES = 0, PF2 = 0, ONE_ATOM = 0;
 };
 struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
                        SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 80, RPAD = 80, SPAD = 0,
-                       PRELOAD_GATES = 0, PF2 = 0;
+                       PRELOAD_GATES = 0, PF2 = 0, ONE_ATOM = 0;
 };
 
 // LDS image of one unit: pixel (row, col) of the source at row*RP + col*CP bf16 elements, units SP apart.  The pixel
@@ -149,10 +149,14 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
   const int fr = lane & 15, fg = lane >> 4;
 
   // ---- weights of this wave's two 16-channel atoms -> registers (A operand: row = fr, k = 32ks + 8fg)
-  const int wrow0 = (L::CLASSES > 1 ? og * L::OUTC : og * 32);
-  u32x4 W[2][L::KS];
+  // NA = 16-channel MFMA atoms per wave.  Two atoms share every LDS fragment (half the LDS reads per MFMA) but their
+  // weights fill the register file for the 18-k-step layers; ONE_ATOM descriptors keep one atom per wave (4 channel
+  // groups of 16) so that the compiler can hold many fragments in flight instead of a read -> MFMA -> read chain.
+  constexpr int NA = L::ONE_ATOM ? 1 : 2, CPW = 16 * NA;
+  const int wrow0 = (L::CLASSES > 1 ? og * L::OUTC : og * CPW);
+  u32x4 W[NA][L::KS];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int ks = 0; ks < L::KS; ++ks)
       // Row fr of atom a is output channel (fr >> 2) * 8 + a * 4 + (fr & 3) of this wave's 32: the MFMA result then
@@ -160,11 +164,11 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
       // channels, so every epilogue access is one 16-byte piece and the 4 lanes of a pixel cover 64 contiguous bytes
       // (8-byte pieces at a 32-byte stride cost conv2 dgrad 40 of its 100 us in partial-line stores).
       W[a][ks] = *reinterpret_cast<const u32x4 *>(
-          P.w + (long)(wrow0 + (fr >> 2) * 8 + a * 4 + (fr & 3)) * K + ks * 32 + fg * 8);
-  const int oc0 = (L::CLASSES > 1 ? 0 : og * 32) + fg * 8; // first of this lane's 8 consecutive output channels
-  float bias_r[2][4];
+          P.w + (long)(wrow0 + (NA == 2 ? (fr >> 2) * 8 + a * 4 + (fr & 3) : fr)) * K + ks * 32 + fg * 8);
+  const int oc0 = (L::CLASSES > 1 ? 0 : og * CPW) + fg * 4 * NA; // first of this lane's 4 NA consecutive output channels
+  float bias_r[NA][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       bias_r[a][r] = (L::MODE == PM_FWD) ? P.bias[oc0 + a * 4 + r] : 0.f;
@@ -283,6 +287,11 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
       const bool qok = atom < NATOM && q < count * L::PIX;
       const int s = min(q / L::PIX, L::SB - 1), p = q - (q / L::PIX) * L::PIX;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      auto mma2 = [&](int ks, const u32x4 &b) {
+        Atom<bf16>::mma(W[0][ks], b, acc0);
+        if constexpr (NA == 2)
+          Atom<bf16>::mma(W[NA - 1][ks], b, acc1);
+      };
       long out_off;
       u32x4 gate = gate_pre;
       if constexpr (L::MODE == PM_FWD) {
@@ -296,8 +305,7 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
           const int koff = L::C >= 32 ? ((ks * 32) / SEG) * RP + (rem / L::C) * L::CP + rem % L::C
                                       : ((ks * 32) / SEG) * RP + rem;
           const u32x4 b = *reinterpret_cast<const u32x4 *>(pb + base + koff);
-          Atom<bf16>::mma(W[0][ks], b, acc0);
-          Atom<bf16>::mma(W[1][ks], b, acc1);
+          mma2(ks, b);
         }
         out_off = ((n0 + s) * L::PIX + p) * (long)L::OUTC + oc0;
       } else {
@@ -311,8 +319,14 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
         // the ReLU gate is fetched BEFORE the MFMA chain: issued in the epilogue its full global-memory latency
         // was exposed once per atom (PMC: 67 % of conv2 dgrad's wave cycles parked in s_waitcnt)
         if constexpr (!PRE)
-          if (qok)
-            gate = *reinterpret_cast<const u32x4 *>(P.act + out_off);
+          if (qok) {
+            if constexpr (NA == 2) {
+              gate = *reinterpret_cast<const u32x4 *>(P.act + out_off);
+            } else {
+              const u32x2 g2 = *reinterpret_cast<const u32x2 *>(P.act + out_off);
+              gate = u32x4{g2[0], g2[1], 0u, 0u};
+            }
+          }
         const int base = s * LPATCH + fg * 8;
         constexpr int KPT = L::OCK / 32; // k-steps per tap
 #pragma unroll
@@ -327,8 +341,7 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
           const int off = base + cy * RP + cx * L::CP + (ks % KPT) * 32;
           u32x4 b = *reinterpret_cast<const u32x4 *>(pb + off);
           b = ok ? b : zero16();
-          Atom<bf16>::mma(W[0][ks], b, acc0);
-          Atom<bf16>::mma(W[1][ks], b, acc1);
+          mma2(ks, b);
         }
       }
       if constexpr (L::MODE == PM_FWD) {
@@ -339,14 +352,17 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v0[r] = fmaxf(acc0[r] * P.scale + bias_r[0][r], 0.f);
-          v1[r] = fmaxf(acc1[r] * P.scale + bias_r[1][r], 0.f);
+          v1[r] = fmaxf(acc1[r] * P.scale + bias_r[NA - 1][r], 0.f);
         }
         const u32x2 lo = pack4_bf16(v0[0], v0[1], v0[2], v0[3]), hi = pack4_bf16(v1[0], v1[1], v1[2], v1[3]);
-        if constexpr (STATIC) {
-          bf16 *dstp = qok ? P.out + out_off : P.dummy + tid * 8;
-          *reinterpret_cast<u32x4 *>(dstp) = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        } else if (qok) {
-          *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        bf16 *dstp = P.out + out_off;
+        if constexpr (STATIC)
+          dstp = qok ? dstp : P.dummy + tid * 8;
+        if (STATIC || qok) {
+          if constexpr (NA == 2)
+            *reinterpret_cast<u32x4 *>(dstp) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          else
+            *reinterpret_cast<u32x2 *>(dstp) = lo;
         }
       } else if (qok) {
         {
@@ -358,7 +374,10 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
                                       gated(gate[1], 1, acc0[3]));
           const u32x2 hi = pack4_bf16(gated(gate[2], 0, acc1[0]), gated(gate[2], 1, acc1[1]), gated(gate[3], 0, acc1[2]),
                                       gated(gate[3], 1, acc1[3]));
-          *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          if constexpr (NA == 2)
+            *reinterpret_cast<u32x4 *>(P.out + out_off) = u32x4{lo[0], lo[1], hi[0], hi[1]};
+          else
+            *reinterpret_cast<u32x2 *>(P.out + out_off) = lo;
         }
       }
     };
@@ -545,13 +564,13 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
 struct LConv2FwdW4 : LConv2Fwd {
   static constexpr int SB = 1;
 };
-struct LConv3FwdW4 : LConv3Fwd {
-  static constexpr int SB = 2; // 2 x 29.5 KB x 2 buffers = 59 KB per workgroup, two workgroups per CU
-};
-struct LConv3DgradW4 : LConv3Dgrad {
-  static constexpr int SB = 4;
-};
 
+// conv3 fwd at training sizes: ONE 16-channel atom per wave (4 channel groups), 2 samples per group = exactly 7 atoms
+// per wave, static atom loop; 4 waves, two workgroups per CU.  33.7 -> 30.1 us: with half the weights in registers
+// the compiler keeps more LDS fragments in flight.  (The same for conv3 dgrad measured slower: 58 vs 45 us.)
+struct LConv3Fwd1W4 : LConv3Fwd {
+  static constexpr int SB = 2, OG = 4, ONE_ATOM = 1, STATIC_ATOMS = 1;
+};
 struct LConv2DgradW4 : LConv2Dgrad {
   static constexpr int SB = 1, PRELOAD_GATES = 1;
 };

@@ -78,7 +78,7 @@ void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float 
   if (ns <= 256)
     launch_patch<LConv3FwdSmall, 8, 1>(s, P);
   else
-    launch_patch<LConv3FwdW4, 4, 2>(s, P);
+    launch_patch<LConv3Fwd1W4, 4, 2>(s, P);
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),
