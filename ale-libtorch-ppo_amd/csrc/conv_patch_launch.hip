@@ -2,6 +2,7 @@
 // Persistent grids: at most one workgroup per CU (the LDS patch buffers are 41..155 KB), 512 threads.
 #include "common.hpp"
 #include "conv_patch.hpp"
+#include "conv3_tile.hpp"
 #include <cstdlib>
 
 namespace aleppo {
@@ -83,6 +84,23 @@ void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float 
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),
                 ns,  SampleMap{1, 0, 0, 0, 0},       1.0f, nullptr};
+  static const int tile = [] {
+    const char *e = std::getenv("ALEPPO_C3D_TILE"); // =0: the sample-stationary kernel (A/B testing: 46 vs 40 us)
+    return e ? std::atoi(e) : 1;
+  }();
+  if (tile) {
+    static bool once = false;
+    if (!once) {
+      allow_smem(conv3_dgrad_tile_kernel, C3T_SMEM);
+      once = true;
+    }
+    C3TileParams T{static_cast<const bf16 *>(dz3), static_cast<const bf16 *>(W3d), static_cast<const bf16 *>(a2),
+                   static_cast<bf16 *>(dz2), fwd_dummy(), ns};
+    const long ngroups = (ns + C3T_SB - 1) / C3T_SB;
+    hipLaunchKernelGGL(conv3_dgrad_tile_kernel, dim3((unsigned)std::min<long>(ngroups, num_cus())), dim3(512), C3T_SMEM, s,
+                       T);
+    return;
+  }
   launch_patch<LConv3Dgrad, 8, 1>(s, P); // the 4-wave / 2-per-CU variant measured slower here (56 vs 48 us)
 }
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns) {

@@ -184,3 +184,15 @@ for SB in (1,2,3):
     search2('conv3fwd SB%d'%SB,lambda CP,RP,SP:fwd2(49,7,1,9,64,3,18,SB,CP,RP,SP),64,9,9,SB,80*1024)
 for SB in (4,8):
     search2('conv3dgrad SB%d clamp'%SB,lambda CP,RP,SP:dgrad4(81,9,7,7,64,3,18,SB,CP,RP,SP),64,7,7,SB,160*1024)
+
+# ---- weight tile of csrc/conv3_tile.hpp: rows stored atom-major, pitch 72 + pad chunks of 16 B
+print("---- conv3 tile kernel: weight fragment reads, pitch = (72 + pad) * 16 B")
+for pad in range(0, 8):
+    pitch = (72 + pad) * 16
+    tot = n = 0
+    for a in range(4):
+        for ks in range(18):
+            ad = [(a * 16 + (lane & 15)) * pitch + (ks * 4 + (lane >> 4)) * 16 for lane in range(64)]
+            tot += cyc(ad)
+            n += 1
+    print(pad, pitch, tot / n)
