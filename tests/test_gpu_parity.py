@@ -286,14 +286,15 @@ def test_bf16_patch_kernels_match_generic_kernels(pkg, N):
     np.testing.assert_allclose(g0 / c0, w["last_grads"] / cw, atol=3e-2 * np.abs(w["last_grads"] / cw).max())
 
 
-@pytest.mark.parametrize("N,M", [(1400, 2), (2048, 2), (4096, 1)])
-def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M):
+@pytest.mark.parametrize("N,M,H", [(1400, 2, 512), (2048, 2, 512), (4096, 1, 512), (1400, 2, 256), (1024, 1, 320)])
+def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M, H):
     """minibatches > 256 samples route the bf16 fc forward / dgrad through the pipelined LDS-DMA GEMM
     (gemm_pipe.hpp); ALEPPO_FC_PIPE=0 keeps the small-tile kernels.  Same bf16 operands, fp32 accumulation in a
     different order (split-K slabs): losses, gradient norm and gradients agree tightly.  700-sample minibatches are
     ragged against the 128-row tiles (identity job map), 1024 / 4096 use the XCD-grouped job map, 4096 gives every
-    workgroup several jobs (the ring streams across tile boundaries)."""
-    H, A = 512, 4
+    workgroup several jobs (the ring streams across tile boundaries).  H = 256 is the shortest K the dgrad ring
+    accepts (4 k-stages); H = 320 has a ragged last 128-column tile in the forward and 5 k-stages."""
+    A = 4
     params = hf.fill_params(910, H, A)
     obs = hf.hf_bytes(911, (N, 4, 84, 84))
     actions = (hf.hf_u32(912, N) % np.uint32(A)).astype(np.int64)
