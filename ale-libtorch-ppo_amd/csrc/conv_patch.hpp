@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
     for (int i = 0; i < 4; ++i)
       R[i] = src[min(tid + 512 * i, 1763)];
   };
-  auto sample = [&](long n) { // widen the staged stack, then conv1 -> conv2 -> conv3 out of LDS
+  auto sample = [&](long n, bool first) { // widen the staged stack, then conv1 -> conv2 -> conv3 out of LDS
     auto pk = [](uint32_t lo, uint32_t hi) { return pack_u8_pair_bf16(lo, hi); };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -533,6 +533,8 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
                             *reinterpret_cast<u32x2 *>(s1 + (q / 20) * PatchGeom<LConv2Fwd>::RP + (q % 20) * LConv2Fwd::CP +
                                                        oc) = v;
                           });
+    if (first) // conv3's weights are requested only now: during conv1 their 72 VGPRs hold fragments in flight instead
+      W3.load(P.w3, P.b3, wave, lane);
     __syncthreads();
     act_phase<LConv2FwdSmall>(s1, W2, 1.0f, wave, lane,
                               [&](int q, int oc, u32x2 v) {
@@ -549,13 +551,12 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   if (n >= P.ns)
     return;
   load_obs(n);
-  W1.load(P.w1, P.b1, wave, lane); // all three layers' weights: issued behind the observation loads, consumed later
+  W1.load(P.w1, P.b1, wave, lane); // conv1 / conv2 weights: issued behind the observation loads, consumed later
   W2.load(P.w2, P.b2, wave, lane);
-  W3.load(P.w3, P.b3, wave, lane);
-  sample(n);
+  sample(n, true);
   for (n += gridDim.x; n < P.ns; n += gridDim.x) {
     load_obs(n);
-    sample(n);
+    sample(n, false);
   }
 }
 
