@@ -461,6 +461,20 @@ template <class L> struct ActW {
     for (int r = 0; r < 4; ++r)
       br[r] = bias[og * 16 + fg * 4 + r];
   }
+  // this wave's atom out of an LDS image of the layer's weights: row r at img + r * PITCH bytes (PITCH = row + 16 B)
+  static constexpr int PITCH = 32 * L::KS * 2 + 16;
+  __device__ __forceinline__ void load_lds(const uint8_t *rows16, int lane) { // rows16: first of the atom's 16 rows
+    const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < L::KS; ++ks)
+      w[ks] = *reinterpret_cast<const u32x4 *>(rows16 + fr * PITCH + ks * 64 + fg * 16);
+  }
+  __device__ __forceinline__ void load_bias(const float *bias, int wave, int lane) {
+    const int og = wave % MA, fg = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      br[r] = bias[og * 16 + fg * 4 + r];
+  }
 };
 // one forward phase out of LDS patch `pb`; writes 4 channels x 1 pixel per lane through `store(q, oc, v4)`
 template <class L, class Store>
@@ -491,19 +505,32 @@ __device__ __forceinline__ void act_phase(const bf16 *pb, const ActW<L> &W, floa
 }
 
 constexpr int ACT_X_ELEMS = 84 * 84 * 4, ACT_A1_ELEMS = PatchGeom<LConv2Fwd>::SP, ACT_A2_ELEMS = PatchGeom<LConv3Fwd>::SP;
-constexpr size_t ACT_SMEM = (size_t)(ACT_X_ELEMS + ACT_A1_ELEMS + ACT_A2_ELEMS) * 2;
+constexpr size_t ACT_ACT_BYTES = (size_t)(ACT_X_ELEMS + ACT_A1_ELEMS + ACT_A2_ELEMS) * 2; // stack + a1 + a2
+constexpr size_t ACT_SMEM = 160 * 1024; // the rest of the LDS stages the layer weights (see act_conv_kernel)
 
+// Weights: every wave needs its 16-channel atom of all three layers in registers (8 + 16 + 18 fragments), and 2-4
+// waves share an atom, so loading straight from global memory moved 336 KB per workgroup - 7.7 of the kernel's 16 us
+// (ablation).  Instead the workgroup copies each layer ONCE (152 KB in all, 19 coalesced 16-byte loads per thread issued
+// at kernel start) and hands it to the waves through LDS regions that are free at that point: conv1's weights in the
+// tail of the LDS, conv2's in the tail + the stack region (dead after conv1), conv3's over stack + a1 (dead after
+// conv2).  Rows are padded by 16 B in LDS (conflict-free fragment reads).
 __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16 *sx = reinterpret_cast<bf16 *>(smem), *s1 = sx + ACT_X_ELEMS, *s2 = s1 + ACT_A1_ELEMS;
+  uint8_t *tail = smem + ACT_ACT_BYTES; // 60 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  ActW<LConv1Full> W1;
-  ActW<LConv2FwdSmall> W2;
-  ActW<LConv3FwdSmall> W3;
+  using A1 = ActW<LConv1Full>;
+  using A2 = ActW<LConv2FwdSmall>;
+  using A3 = ActW<LConv3FwdSmall>;
+  static_assert(32 * A1::PITCH <= ACT_SMEM - ACT_ACT_BYTES && 32 * A2::PITCH <= ACT_SMEM - ACT_ACT_BYTES &&
+                    32 * A2::PITCH <= ACT_X_ELEMS * 2 && 64 * A3::PITCH <= (ACT_X_ELEMS + ACT_A1_ELEMS) * 2,
+                "LDS regions for the weight images");
+  A1 W1;
+  A2 W2;
+  A3 W3;
   u32x4 R[4];
   // packed u8 stack of sample n: 1764 16-byte vectors.  UNCONDITIONAL loads (index clamped): hipcc can then count
-  // them and wait for these four alone while the 42 weight loads issued behind them stay in flight (with a
-  // predicated load it drained the whole queue - all three layers' weights - before widening the observation).
+  // them and wait for these four alone while the weight loads issued behind them stay in flight.
   auto load_obs = [&](long n) {
     const long nn = n + P.map.n0;
     const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base;
@@ -512,7 +539,7 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
     for (int i = 0; i < 4; ++i)
       R[i] = src[min(tid + 512 * i, 1763)];
   };
-  auto sample = [&](long n, bool first) { // widen the staged stack, then conv1 -> conv2 -> conv3 out of LDS
+  auto widen = [&]() {
     auto pk = [](uint32_t lo, uint32_t hi) { return pack_u8_pair_bf16(lo, hi); };
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -527,36 +554,82 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
         }
       }
     }
-    __syncthreads();
-    act_phase<LConv1Full>(sx, W1, 1.0f / 255.0f, wave, lane,
-                          [&](int q, int oc, u32x2 v) {
-                            *reinterpret_cast<u32x2 *>(s1 + (q / 20) * PatchGeom<LConv2Fwd>::RP + (q % 20) * LConv2Fwd::CP +
-                                                       oc) = v;
-                          });
-    if (first) // conv3's weights are requested only now: during conv1 their 72 VGPRs hold fragments in flight instead
-      W3.load(P.w3, P.b3, wave, lane);
-    __syncthreads();
-    act_phase<LConv2FwdSmall>(s1, W2, 1.0f, wave, lane,
-                              [&](int q, int oc, u32x2 v) {
-                                *reinterpret_cast<u32x2 *>(s2 + (q / 9) * PatchGeom<LConv3Fwd>::RP +
-                                                           (q % 9) * LConv3Fwd::CP + oc) = v;
-                              });
-    __syncthreads();
+  };
+  auto conv1 = [&]() {
+    act_phase<LConv1Full>(sx, W1, 1.0f / 255.0f, wave, lane, [&](int q, int oc, u32x2 v) {
+      *reinterpret_cast<u32x2 *>(s1 + (q / 20) * PatchGeom<LConv2Fwd>::RP + (q % 20) * LConv2Fwd::CP + oc) = v;
+    });
+  };
+  auto conv2 = [&]() {
+    act_phase<LConv2FwdSmall>(s1, W2, 1.0f, wave, lane, [&](int q, int oc, u32x2 v) {
+      *reinterpret_cast<u32x2 *>(s2 + (q / 9) * PatchGeom<LConv3Fwd>::RP + (q % 9) * LConv3Fwd::CP + oc) = v;
+    });
+  };
+  auto conv3 = [&](long n) {
     bf16 *out = P.a3 + n * (long)(49 * 64);
     act_phase<LConv3FwdSmall>(s2, W3, 1.0f, wave, lane,
                               [&](int q, int oc, u32x2 v) { *reinterpret_cast<u32x2 *>(out + q * 64 + oc) = v; });
-    __syncthreads();
   };
+  // vector v of a layer's flat [rows][K] weight array -> its place in an LDS image with padded rows
+  auto img_off = [](int v, int vpr, int pitch) { return (v / vpr) * pitch + (v % vpr) * 16; };
+
   long n = blockIdx.x;
   if (n >= P.ns)
     return;
+  // ---- first sample: observation + ONE copy of every layer's weights per workgroup, all requested up front
   load_obs(n);
-  W1.load(P.w1, P.b1, wave, lane); // conv1 / conv2 weights: issued behind the observation loads, consumed later
-  W2.load(P.w2, P.b2, wave, lane);
-  sample(n, true);
+  u32x4 S1[2], S2[8], S3[9];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    S1[i] = reinterpret_cast<const u32x4 *>(P.w1)[tid + 512 * i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    S2[i] = reinterpret_cast<const u32x4 *>(P.w2)[tid + 512 * i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    S3[i] = reinterpret_cast<const u32x4 *>(P.w3)[tid + 512 * i];
+  W1.load_bias(P.b1, wave, lane);
+  W2.load_bias(P.b2, wave, lane);
+  W3.load_bias(P.b3, wave, lane);
+  widen();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) // conv1 weights [32][256] -> tail
+    *reinterpret_cast<u32x4 *>(tail + img_off(tid + 512 * i, 32, A1::PITCH)) = S1[i];
+  __syncthreads();
+  W1.load_lds(tail + (wave % A1::MA) * 16 * A1::PITCH, lane);
+  conv1();
+  __syncthreads(); // stack and conv1's weight image are dead
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { // conv2 weights [64][512]: rows 0-31 -> tail, rows 32-63 -> stack region
+    const int v = tid + 512 * i, row = v / 64;
+    uint8_t *dst = row < 32 ? tail : smem - 32 * A2::PITCH;
+    *reinterpret_cast<u32x4 *>(dst + img_off(v, 64, A2::PITCH)) = S2[i];
+  }
+  __syncthreads();
+  {
+    const int og = wave % A2::MA;
+    W2.load_lds((og < 2 ? tail : smem - 32 * A2::PITCH) + og * 16 * A2::PITCH, lane);
+  }
+  conv2();
+  __syncthreads(); // a1 and conv2's weight image are dead
+#pragma unroll
+  for (int i = 0; i < 9; ++i) // conv3 weights [64][576] -> stack + a1 region
+    *reinterpret_cast<u32x4 *>(smem + img_off(tid + 512 * i, 72, A3::PITCH)) = S3[i];
+  __syncthreads();
+  W3.load_lds(smem + (wave % A3::MA) * 16 * A3::PITCH, lane);
+  conv3(n);
+  __syncthreads();
+  // ---- further samples of this workgroup (more environments than CUs): the weights stay in registers
   for (n += gridDim.x; n < P.ns; n += gridDim.x) {
     load_obs(n);
-    sample(n, false);
+    widen();
+    __syncthreads();
+    conv1();
+    __syncthreads();
+    conv2();
+    __syncthreads();
+    conv3(n);
+    __syncthreads();
   }
 }
 
