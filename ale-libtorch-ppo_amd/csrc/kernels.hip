@@ -152,33 +152,49 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
   extern __shared__ float sWh[]; // [(A+1)][H] head weights: ONE parallel round trip for the whole workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 4 + wave;
-  float hv[8]; // H <= 512
-  float part[8][NSPLIT];
+  // Lane l owns hidden units 8l .. 8l+7 (H <= 512, H % 8 == 0): two 16-byte loads per split-K slice instead of eight
+  // scalar ones (the kernel is latency-bound on ~70 vector-memory instructions per wave; now 18).
+  float hv[8];
+  f32x4 part[NSPLIT][2];
+  const bool own = e < E && lane * 8 < H;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { // issue every split-K partial load first (independent)
-    const int j = lane + 64 * i;
-#pragma unroll
-    for (int z = 0; z < NSPLIT; ++z)
-      part[i][z] = (e < E && j < H) ? hpart[((size_t)z * E + e) * H + j] : 0.f;
-    hv[i] = (e < E && j < H) ? bfc[j] : 0.f;
+  for (int z = 0; z < NSPLIT; ++z) { // issue every split-K partial load first (independent)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(hpart + ((size_t)z * E + (own ? e : 0)) * H + (own ? lane * 8 : 0));
+    part[z][0] = src[0];
+    part[z][1] = src[1];
   }
-  for (int k = threadIdx.x; k < (A + 1) * H; k += 256)
-    sWh[k] = Wh[k];
+  {
+    const f32x4 *b = reinterpret_cast<const f32x4 *>(bfc + (own ? lane * 8 : 0));
+    const f32x4 b0 = b[0], b1 = b[1];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i) {
+      hv[i] = b0[i];
+      hv[4 + i] = b1[i];
+    }
+  }
+  for (int k = threadIdx.x; k < (A + 1) * H / 4; k += 256)
+    reinterpret_cast<f32x4 *>(sWh)[k] = reinterpret_cast<const f32x4 *>(Wh)[k];
 #pragma unroll
-    for (int z = 0; z < NSPLIT; ++z)
-      hv[i] += part[i][z];
+  for (int z = 0; z < NSPLIT; ++z)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hv[i] += part[z][0][i];
+      hv[4 + i] += part[z][1][i];
+    }
   __syncthreads();
   if (e < E) {
     float zmine = 0.f; // lane a keeps logit a (a < A) / the value (a == A)
     for (int a = 0; a <= A; ++a) {
       float s = 0.f;
+      if (lane * 8 < H) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sWh + a * H + lane * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sWh + a * H + lane * 8 + 4);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int j = lane + 64 * i;
-        if (j < H)
-          s += hv[i] * sWh[a * H + j];
+        for (int i = 0; i < 4; ++i)
+          s += hv[i] * w0[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          s += hv[4 + i] * w1[i];
       }
       s = wave_sum(s) + bh[a];
       if (lane == a)
