@@ -482,16 +482,20 @@ __global__ __launch_bounds__(512) void head_train_kernel(
   bool mask_n = false;
   auto fetch = [&](long r) {
     const bool ok = r < row1;
+    // lane l owns hidden units 8l .. 8l+7 (H % 8 == 0): 16-byte loads / stores instead of 8 scalar ones per row
 #pragma unroll
-    for (int i = 0; i < HPL; ++i) {
-      const int j = lane + 64 * i;
-      float v = 0.f;
-      if (ok && j < H) { // h arrives as `hparts` split-K partial slabs [hparts][B][H] (slab 0 carries the bias)
-        v = h[(size_t)r * H + j];
-        for (int p = 1; p < hparts; ++p)
-          v += h[((size_t)p * B + r) * H + j];
+    for (int i = 0; i < HPL; ++i)
+      hnext[i] = 0.f;
+    if (ok && lane * 8 < H) { // h arrives as `hparts` split-K partial slabs [hparts][B][H] (slab 0 carries the bias)
+      for (int p = 0; p < hparts; ++p) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(h + ((size_t)p * B + r) * H + lane * 8);
+        const f32x4 v0 = src[0], v1 = src[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          hnext[i] += v0[i];
+          hnext[4 + i] += v1[i];
+        }
       }
-      hnext[i] = v;
     }
 #pragma unroll
     for (int a = 0; a < AMAX; ++a)
@@ -534,11 +538,15 @@ __global__ __launch_bounds__(512) void head_train_kernel(
     for (int a = 0; a < A1; ++a) {
       float s = 0.f;
       if (a <= A) {
+        if (lane * 8 < H) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8);
+          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8 + 4);
 #pragma unroll
-        for (int i = 0; i < HPL; ++i) {
-          const int j = lane + 64 * i;
-          if (j < H)
-            s += hv[i] * sW[a * H + j];
+          for (int i = 0; i < 4; ++i)
+            s += hv[i] * w0[i];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            s += hv[4 + i] * w1[i];
         }
         s = wave_sum(s) + bh[a];
       }
@@ -615,20 +623,37 @@ __global__ __launch_bounds__(512) void head_train_kernel(
       }
     }
     // head dgrad: dh = sum_a dz[a] * W[a][:]   and wgrad partial: gW[a][:] += dz[a] * h
+    if (lane * 8 < H) {
+      float d[HPL];
 #pragma unroll
-    for (int i = 0; i < HPL; ++i) {
-      const int j = lane + 64 * i;
-      if (j < H) {
-        float d = 0.f;
+      for (int i = 0; i < HPL; ++i)
+        d[i] = 0.f;
 #pragma unroll
-        for (int a = 0; a < A1; ++a)
-          if (a <= A) {
-            d += dz[a] * sW[a * H + j];
-            gW[a][i] += dz[a] * hv[i];
+      for (int a = 0; a < A1; ++a)
+        if (a <= A) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8);
+          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8 + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            d[i] += dz[a] * w0[i];
+            d[4 + i] += dz[a] * w1[i];
           }
-        const T dr = (T)d;
-        dh[(size_t)row * H + j] = dr;
-        gfc[i] += (float)dr; // the rounded value the fc wgrad GEMM multiplies with
+#pragma unroll
+          for (int i = 0; i < HPL; ++i)
+            gW[a][i] += dz[a] * hv[i];
+        }
+      T dr[HPL];
+#pragma unroll
+      for (int i = 0; i < HPL; ++i) {
+        dr[i] = (T)d[i];
+        gfc[i] += (float)dr[i]; // the rounded value the fc wgrad GEMM multiplies with
+      }
+      T *dst = dh + (size_t)row * H + lane * 8;
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(dr);
+      } else {
+        reinterpret_cast<u32x4 *>(dst)[0] = reinterpret_cast<const u32x4 *>(dr)[0];
+        reinterpret_cast<u32x4 *>(dst)[1] = reinterpret_cast<const u32x4 *>(dr)[1];
       }
     }
 #pragma unroll
@@ -645,7 +670,7 @@ __global__ __launch_bounds__(512) void head_train_kernel(
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < HPL; ++i) {
-        const int j = lane + 64 * i;
+        const int j = lane * 8 + i;
         if (j < H)
           sPart[wave * H + j] = gW[a][i];
       }
@@ -672,7 +697,7 @@ __global__ __launch_bounds__(512) void head_train_kernel(
   if (slab_bfc) { // same fixed-order cross-wave reduction for the fc bias gradient
 #pragma unroll
     for (int i = 0; i < HPL; ++i) {
-      const int j = lane + 64 * i;
+      const int j = lane * 8 + i;
       if (j < H)
         sPart[wave * H + j] = gfc[i];
     }
