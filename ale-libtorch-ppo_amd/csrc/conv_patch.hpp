@@ -836,8 +836,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
 #pragma unroll
       for (int i = 0; i < L::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < L::NI; ++j) // im2col fragment as the "A" operand: acc[i][j][r] = dW[m = ..+li][n = ..+4 lg + r]
-          Atom<bf16>::mma(fb[j], fa[i], acc[i][j]);
+        for (int j = 0; j < L::NI; ++j)
+          Atom<bf16>::mma(fa[i], fb[j], acc[i][j]);
     }
   };
   // iteration i multiplies LDS buffer i & 1 (group g_i), then stages group g_{i+1} from register set (i+1) & 1 and
@@ -874,14 +874,15 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   }
   // ---- one slab per workgroup
   float *ow = P.slab_w + (long)blockIdx.x * L::OC * L::NJ;
-  // a lane holds 4 CONSECUTIVE n of one row m (operands swapped above): one 16-byte store per accumulator
 #pragma unroll
-  for (int i = 0; i < L::MI; ++i) {
-    const int m = (wm * L::MI + i) * 16 + li;
+  for (int i = 0; i < L::MI; ++i)
 #pragma unroll
-    for (int j = 0; j < L::NI; ++j)
-      *reinterpret_cast<f32x4 *>(ow + (long)m * L::NJ + (wn * L::NI + j) * 16 + lg * 4) = acc[i][j] * P.scale;
-  }
+    for (int r = 0; r < 4; ++r) {
+      const int m = (wm * L::MI + i) * 16 + lg * 4 + r;
+#pragma unroll
+      for (int j = 0; j < L::NI; ++j)
+        ow[(long)m * L::NJ + (wn * L::NI + j) * 16 + li] = acc[i][j][r] * P.scale;
+    }
   // bias: threads with equal tid % VPR hold the same 8 channels; ordered LDS reduction (deterministic)
   __syncthreads();
   float *red = reinterpret_cast<float *>(smem);
