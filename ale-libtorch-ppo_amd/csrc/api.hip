@@ -395,6 +395,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
 
 extern "C" int aleppo_synchronize(aleppo_ctx *c) {
   CHECK_CTX(c);
+  HIPCHK(c, hipStreamSynchronize(c->wg_stream));
   HIPCHK(c, hipStreamSynchronize(c->comm_stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ALEPPO_OK;
