@@ -152,20 +152,21 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
   extern __shared__ float sWh[]; // [(A+1)][H] head weights: ONE parallel round trip for the whole workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 4 + wave;
-  // Lane l owns hidden units 8l .. 8l+7 (H <= 512, H % 8 == 0): two 16-byte loads per split-K slice instead of eight
-  // scalar ones (the kernel is latency-bound on ~70 vector-memory instructions per wave; now 18).
+  // Lane l owns hidden units 4l .. 4l+3 and H/2 + 4l .. (H <= 512, H % 8 == 0): two 16-byte loads per split-K slice
+  // instead of eight scalar ones (the kernel is latency-bound on ~70 vector-memory instructions per wave; now 18),
+  // consecutive lanes on consecutive 16-byte pieces (coalesced, conflict-free LDS reads of the head weights).
   float hv[8];
   f32x4 part[NSPLIT][2];
   const bool own = e < E && lane * 8 < H;
 #pragma unroll
   for (int z = 0; z < NSPLIT; ++z) { // issue every split-K partial load first (independent)
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(hpart + ((size_t)z * E + (own ? e : 0)) * H + (own ? lane * 8 : 0));
-    part[z][0] = src[0];
-    part[z][1] = src[1];
+    const float *src = hpart + ((size_t)z * E + (own ? e : 0)) * H + (own ? lane * 4 : 0);
+    part[z][0] = *reinterpret_cast<const f32x4 *>(src);
+    part[z][1] = *reinterpret_cast<const f32x4 *>(src + H / 2);
   }
   {
-    const f32x4 *b = reinterpret_cast<const f32x4 *>(bfc + (own ? lane * 8 : 0));
-    const f32x4 b0 = b[0], b1 = b[1];
+    const float *b = bfc + (own ? lane * 4 : 0);
+    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b), b1 = *reinterpret_cast<const f32x4 *>(b + H / 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       hv[i] = b0[i];
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
     for (int a = 0; a <= A; ++a) {
       float s = 0.f;
       if (lane * 8 < H) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sWh + a * H + lane * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sWh + a * H + lane * 8 + 4);
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sWh + a * H + lane * 4);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sWh + a * H + H / 2 + lane * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           s += hv[i] * w0[i];
@@ -482,14 +483,15 @@ __global__ __launch_bounds__(512) void head_train_kernel(
   bool mask_n = false;
   auto fetch = [&](long r) {
     const bool ok = r < row1;
-    // lane l owns hidden units 8l .. 8l+7 (H % 8 == 0): 16-byte loads / stores instead of 8 scalar ones per row
+    // lane l owns hidden units 4l .. 4l+3 and H/2 + 4l .. H/2 + 4l+3 (H % 8 == 0): 16-byte loads instead of scalar
+    // ones, and consecutive lanes touch consecutive 16-byte pieces (coalesced; conflict-free LDS reads of the weights)
 #pragma unroll
     for (int i = 0; i < HPL; ++i)
       hnext[i] = 0.f;
     if (ok && lane * 8 < H) { // h arrives as `hparts` split-K partial slabs [hparts][B][H] (slab 0 carries the bias)
       for (int p = 0; p < hparts; ++p) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(h + ((size_t)p * B + r) * H + lane * 8);
-        const f32x4 v0 = src[0], v1 = src[1];
+        const float *src = h + ((size_t)p * B + r) * H + lane * 4;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + H / 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           hnext[i] += v0[i];
@@ -539,8 +541,8 @@ __global__ __launch_bounds__(512) void head_train_kernel(
       float s = 0.f;
       if (a <= A) {
         if (lane * 8 < H) {
-          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8);
-          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8 + 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 4);
+          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + a * H + H / 2 + lane * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             s += hv[i] * w0[i];
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(512) void head_train_kernel(
 #pragma unroll
       for (int a = 0; a < A1; ++a)
         if (a <= A) {
-          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8);
-          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 8 + 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sW + a * H + lane * 4);
+          const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sW + a * H + H / 2 + lane * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             d[i] += dz[a] * w0[i];
@@ -648,12 +650,13 @@ __global__ __launch_bounds__(512) void head_train_kernel(
         dr[i] = (T)d[i];
         gfc[i] += (float)dr[i]; // the rounded value the fc wgrad GEMM multiplies with
       }
-      T *dst = dh + (size_t)row * H + lane * 8;
+      T *dst = dh + (size_t)row * H + lane * 4;
       if constexpr (sizeof(T) == 2) {
-        *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(dr);
+        *reinterpret_cast<u32x2 *>(dst) = reinterpret_cast<const u32x2 *>(dr)[0];
+        *reinterpret_cast<u32x2 *>(dst + H / 2) = reinterpret_cast<const u32x2 *>(dr)[1];
       } else {
-        reinterpret_cast<u32x4 *>(dst)[0] = reinterpret_cast<const u32x4 *>(dr)[0];
-        reinterpret_cast<u32x4 *>(dst)[1] = reinterpret_cast<const u32x4 *>(dr)[1];
+        *reinterpret_cast<u32x4 *>(dst) = reinterpret_cast<const u32x4 *>(dr)[0];
+        *reinterpret_cast<u32x4 *>(dst + H / 2) = reinterpret_cast<const u32x4 *>(dr)[1];
       }
     }
 #pragma unroll
@@ -670,8 +673,8 @@ __global__ __launch_bounds__(512) void head_train_kernel(
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < HPL; ++i) {
-        const int j = lane * 8 + i;
-        if (j < H)
+        const int j = (i < 4 ? 0 : H / 2) + lane * 4 + (i & 3);
+        if (lane * 8 < H)
           sPart[wave * H + j] = gW[a][i];
       }
       if (lane == 0)
@@ -697,8 +700,8 @@ __global__ __launch_bounds__(512) void head_train_kernel(
   if (slab_bfc) { // same fixed-order cross-wave reduction for the fc bias gradient
 #pragma unroll
     for (int i = 0; i < HPL; ++i) {
-      const int j = lane * 8 + i;
-      if (j < H)
+      const int j = (i < 4 ? 0 : H / 2) + lane * 4 + (i & 3);
+      if (lane * 8 < H)
         sPart[wave * H + j] = gfc[i];
     }
     __syncthreads();
