@@ -40,6 +40,9 @@ KERNEL_CLASSES = dict(ingest=0, gae=1, head=2, adam=3, conv1_fwd=4, conv2_fwd=5,
                       reduce=15, infer_head=16)
 
 # every symbol include/aleppo.h declares (checked by tests/test_abi.py against the header text)
+# aleppo_set_option keys (include/aleppo.h)
+OPT_GENERIC_CONV, OPT_DEBUG_NO_PUBLISH, OPT_FORCE_COMM, OPT_SERIAL_UPDATE = 0, 1, 2, 3
+
 EXPORTS = [
     "aleppo_abi_version", "aleppo_create", "aleppo_destroy", "aleppo_last_error", "aleppo_param_count",
     "aleppo_load_params", "aleppo_export_params", "aleppo_export_grads", "aleppo_act", "aleppo_push_frames",

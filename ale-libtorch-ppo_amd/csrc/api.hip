@@ -133,9 +133,11 @@ template <class T> static hipError_t dalloc(T **p, size_t bytes) {
   return e;
 }
 
-static void prof_begin(Ctx *c, int cls) {
+static void prof_begin(Ctx *c, int cls, hipStream_t st = nullptr) {
   if (!c->prof_on)
     return;
+  if (!st)
+    st = c->stream;
   ProfClass &p = c->prof[cls];
   if (p.used == p.start.size()) {
     hipEvent_t a, b;
@@ -144,13 +146,15 @@ static void prof_begin(Ctx *c, int cls) {
     p.start.push_back(a);
     p.stop.push_back(b);
   }
-  hipEventRecord(p.start[p.used], c->stream);
+  hipEventRecord(p.start[p.used], st);
 }
-static void prof_end(Ctx *c, int cls) {
+static void prof_end(Ctx *c, int cls, hipStream_t st = nullptr) { // same stream as the matching prof_begin
   if (!c->prof_on)
     return;
+  if (!st)
+    st = c->stream;
   ProfClass &p = c->prof[cls];
-  hipEventRecord(p.stop[p.used], c->stream);
+  hipEventRecord(p.stop[p.used], st);
   p.used++;
 }
 
@@ -785,7 +789,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   const int nblk_head = (int)std::min<long>(MAXS_HEAD, (B + 15) / 16);
   const int nblk_sq = (int)std::min<size_t>(1024, (L.total() + 4095) / 4096);
 
-  // Unless profiling, the three weight-gradient kernels (and the slab reduce of bucket 0) run on their own stream
+  // The three weight-gradient kernels (and the slab reduce of bucket 0) run on their own stream
   // next to the dgrad chain (fc wgrad || fc dgrad, conv3 wgrad || conv3 dgrad, conv2 wgrad || conv2 dgrad -> conv1
   // wgrad).  Every kernel is a latency-bound full-GPU persistent grid: co-scheduling fills the drain / ramp bubbles
   // between dependent launches.
@@ -793,7 +797,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     const char *e = std::getenv("ALEPPO_BWD_STREAMS");
     return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
-  const bool two = two_env && !c->prof_on;
+  const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
   auto fork = [&](hipEvent_t ev) { // sw continues after everything enqueued on s so far
     if (two) {
@@ -825,12 +829,12 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_begin(c, ALEPPO_K_FC_DGRAD);
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
       prof_end(c, ALEPPO_K_FC_DGRAD);
-      prof_begin(c, ALEPPO_K_FC_WGRAD);
+      prof_begin(c, ALEPPO_K_FC_WGRAD, sw);
       // split-K slabs (or, with one slice, straight into the gradient tensor)
       const bool fc_direct = !wg_pipe && fc_wgrad_slices(prec, B) == 1;
       const int Sfc = fc_wgrad(sw, prec, c->dh, c->a3, fc_direct ? c->G + L.off[P_WFC] : sWfc,
                                fc_direct ? c->G + L.off[P_BFC] : sBfc, B, H);
-      prof_end(c, ALEPPO_K_FC_WGRAD);
+      prof_end(c, ALEPPO_K_FC_WGRAD, sw);
       // bucket 0 = heads + fc.  With data parallelism it is reduced now so that its all-reduce overlaps the conv
       // backward; on one GPU all ten slab groups are reduced by ONE launch after the conv wgrads.
       const ReduceSeg segs0[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
@@ -842,9 +846,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       // measured slower (8.60 vs 8.38 ms per update) than one reduce of all ten slab groups at the end
       const bool early0 = dp;
       if (early0) {
-        prof_begin(c, ALEPPO_K_REDUCE);
+        prof_begin(c, ALEPPO_K_REDUCE, sw);
         launch_reduce_slabs(sw, segs0, nseg0, c->G);
-        prof_end(c, ALEPPO_K_REDUCE);
+        prof_end(c, ALEPPO_K_REDUCE, sw);
       }
       if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs
         HIPCHK(c, hipEventRecord(c->ev_bucket0, sw));
@@ -856,16 +860,16 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_begin(c, ALEPPO_K_CONV3_DGRAD);
       conv3_dgrad(s, prec, c->dz3, c->W3d, c->a2, c->dz2, B);
       prof_end(c, ALEPPO_K_CONV3_DGRAD);
-      prof_begin(c, ALEPPO_K_CONV3_WGRAD);
+      prof_begin(c, ALEPPO_K_CONV3_WGRAD, sw);
       const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
-      prof_end(c, ALEPPO_K_CONV3_WGRAD);
+      prof_end(c, ALEPPO_K_CONV3_WGRAD, sw);
       fork(c->ev_dz2); // dz2 is ready
       prof_begin(c, ALEPPO_K_CONV2_DGRAD);
       conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
       prof_end(c, ALEPPO_K_CONV2_DGRAD);
-      prof_begin(c, ALEPPO_K_CONV2_WGRAD);
+      prof_begin(c, ALEPPO_K_CONV2_WGRAD, sw);
       const int S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
-      prof_end(c, ALEPPO_K_CONV2_WGRAD);
+      prof_end(c, ALEPPO_K_CONV2_WGRAD, sw);
       // conv1 wgrad is the last link of the dgrad chain and runs alone on s: meanwhile the wgrad stream reduces every
       // slab group that is already complete (conv3, conv2 and - on one GPU - heads + fc); only conv1's slabs are left
       // for the reduce after the join.
@@ -876,9 +880,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         for (int i = 0; i < nseg0; ++i)
           segs[nseg++] = segs0[i];
       if (two) {
-        prof_begin(c, ALEPPO_K_REDUCE);
+        prof_begin(c, ALEPPO_K_REDUCE, sw);
         launch_reduce_slabs(sw, segs, nseg, c->G);
-        prof_end(c, ALEPPO_K_REDUCE);
+        prof_end(c, ALEPPO_K_REDUCE, sw);
         nseg = 0;
       }
       prof_begin(c, ALEPPO_K_CONV1_WGRAD);
@@ -1126,6 +1130,8 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     set_patch_kernels(value == 0);
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
+  else if (option == ALEPPO_OPT_SERIAL_UPDATE)
+    c->serial_update = value != 0;
   else if (option == ALEPPO_OPT_FORCE_COMM)
     c->force_comm = value != 0;
   else

@@ -127,6 +127,7 @@ struct Ctx {
   long last_B = 0;
   // ---- profiling ----
   bool prof_on = false;
+  bool serial_update = false; // ALEPPO_OPT_SERIAL_UPDATE: every update kernel on the main stream
   bool dbg_no_publish = false;
   bool force_comm = false;
   ProfClass prof[ALEPPO_K_COUNT];

@@ -187,8 +187,13 @@ def run(args):
         rollout_only()
         act = {k: eng.profile_read(k) for k in pkg.KERNEL_CLASSES}
         eng.profile_reset()
-        eng.train(2.5e-4, epochs, M)
+        eng.train(2.5e-4, epochs, M)  # the timed region's schedule: wgrad kernels + slab reduce on a second stream
         trn = {k: eng.profile_read(k) for k in pkg.KERNEL_CLASSES}
+        eng.profile_reset()
+        pkg.lib().aleppo_set_option(eng._ctx, pkg.OPT_SERIAL_UPDATE, 1)
+        eng.train(2.5e-4, epochs, M)  # every kernel alone on the main stream: its own efficiency
+        iso = {k: eng.profile_read(k) for k in pkg.KERNEL_CLASSES}
+        pkg.lib().aleppo_set_option(eng._ctx, pkg.OPT_SERIAL_UPDATE, 0)
         eng.profile(False)
         B = E * T // M
         KB = kernel_bytes(args.dtype)
@@ -226,6 +231,19 @@ def run(args):
         roofline["update_all_kernels_TFLOPs"] = round(sum(KFLOP.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e12, 2)
         roofline["update_all_kernels_GBps"] = round(sum(KB.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e9, 1)
         roofline["update_kernels"] = table
+        iso_tab = {}
+        for k in KFLOP:  # the same table with every kernel running alone (ALEPPO_OPT_SERIAL_UPDATE)
+            ms = iso[k][0]
+            if ms:
+                t_mfma, t_hbm = KFLOP[k] * B / (peak_tf * 1e12), KB[k] * B / (PEAK_HBM_GBS * 1e9)
+                iso_tab[k] = dict(ms=round(ms, 4), GBps=round(KB[k] * B / (ms * 1e-3) / 1e9, 1),
+                                  TFLOPs=round(KFLOP[k] * B / (ms * 1e-3) / 1e12, 1),
+                                  frac=round(max(t_hbm, t_mfma) / (ms * 1e-3), 4))
+        roofline["update_kernels_isolated"] = iso_tab
+        roofline["isolated"] = dict(kernel=dom, avg_launch_ms=iso_tab[dom]["ms"], frac=iso_tab[dom]["frac"],
+                                    achieved=iso_tab[dom]["GBps"] if d["bound"] == "hbm" else iso_tab[dom]["TFLOPs"],
+                                    note="same kernel alone on the GPU; in the timed region it shares the GPU with the "
+                                         "kernels co-scheduled on the second stream")
         roofline["update_other_kernel_ms"] = {k: round(v[0], 4) for k, v in trn.items() if v[1] and k not in KFLOP}
         roofline["acting_kernel_ms_per_step"] = {k: round(v[0], 4) for k, v in act.items() if v[1]}
         ing_ms = act["ingest"][0]

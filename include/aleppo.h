@@ -261,7 +261,9 @@ int aleppo_profile_reset(aleppo_ctx *ctx);
 typedef enum {
   ALEPPO_OPT_GENERIC_CONV = 0,
   ALEPPO_OPT_DEBUG_NO_PUBLISH = 1, /* diagnosis only: the head kernel skips the pinned-memory hand-off */
-  ALEPPO_OPT_FORCE_COMM = 2        /* tests: run the RCCL all-reduce path even with a 1-rank communicator */
+  ALEPPO_OPT_FORCE_COMM = 2,       /* tests: run the RCCL all-reduce path even with a 1-rank communicator */
+  ALEPPO_OPT_SERIAL_UPDATE = 3     /* measurement: run the weight-gradient kernels on the main stream too (isolated
+                                      per-kernel timings; default 0 = co-scheduled on a second stream) */
 } aleppo_option;
 int aleppo_set_option(aleppo_ctx *ctx, int option, int value);
 /* Block until everything enqueued on ctx's streams has finished. */

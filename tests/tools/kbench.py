@@ -16,6 +16,8 @@ N = E * T
 obs = rng.integers(0, 256, (N, 4, 84, 84), dtype=np.uint8)
 eng.set_batch(obs, rng.integers(0, A, N), np.full((N, A), -np.log(A), np.float32), rng.standard_normal(N).astype(np.float32),
               rng.standard_normal(N).astype(np.float32), np.ones(N, np.uint8))
+if not os.environ.get("KB_COSCHED"):  # isolated per-kernel times: every kernel alone on the main stream
+    pkg.lib().aleppo_set_option(eng._ctx, pkg.OPT_SERIAL_UPDATE, 1)
 eng.train(2.5e-4, 1, M)
 eng.profile(True); eng.profile_reset()
 eng.train(2.5e-4, 2, M)
