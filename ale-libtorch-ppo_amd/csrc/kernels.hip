@@ -757,23 +757,69 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
 // ================================================================================================
 struct ReduceArgs {
   ReduceSeg seg[12];
-  int cprefix[13]; // prefix of 64-output chunks per segment
+  int cprefix[13]; // prefix of workgroups per segment
+  int wide[12];    // segment runs the 16-byte path (1024 outputs per workgroup)
   int nseg;
 };
-// one workgroup per 64 consecutive outputs: thread (o = tid&63, q = tid>>6) sums slabs q, q+4, ... and the
-// four partials are combined in fixed order -> deterministic, 4x the memory-level parallelism of a serial scan
+// Two shapes of work in one launch, chosen per segment on the host:
+//  * narrow (small n, many slabs - the conv wgrads): one workgroup per 64 consecutive outputs, thread
+//    (o = tid&63, q = tid>>6) sums slabs q, q+4, ... and the four partials are combined in fixed order
+//    -> 4x the memory-level parallelism of a serial scan;
+//  * wide (the fc weight: 1.6 M outputs, <= 4 slabs): one workgroup per 1024 outputs, every thread sums a
+//    float4 column with 16-byte loads, keeping the same four interleaved partial sums per output.
+// Both give the value ((s0+s4+..) + (s1+s5+..)) + ((s2+..) + (s3+..)) -> identical bits, run-to-run deterministic.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(ReduceArgs a, float *G) {
   __shared__ float part[4][64];
   int s = 0;
   while ((int)blockIdx.x >= a.cprefix[s + 1])
     ++s;
+  const long n = a.seg[s].n;
+  const int S = a.seg[s].S;
+  if (a.wide[s]) { // workgroup-uniform
+    const long j = ((long)((int)blockIdx.x - a.cprefix[s]) * 256 + threadIdx.x) * 4;
+    if (j >= n)
+      return;
+    const float *p = a.seg[s].slab + j;
+    float4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        v[q] = *reinterpret_cast<const float4 *>(p + (long)(k + q) * n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q].x += v[q].x;
+        acc[q].y += v[q].y;
+        acc[q].z += v[q].z;
+        acc[q].w += v[q].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (k + q < S) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + (long)(k + q) * n);
+        acc[q].x += v.x;
+        acc[q].y += v.y;
+        acc[q].z += v.z;
+        acc[q].w += v.w;
+      }
+    float4 r;
+    r.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+    r.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    r.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+    r.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+    *reinterpret_cast<float4 *>(G + a.seg[s].dst + j) = r;
+    return;
+  }
   const long j = (long)((int)blockIdx.x - a.cprefix[s]) * 64 + (threadIdx.x & 63);
   const int q = threadIdx.x >> 6;
-  const long n = a.seg[s].n;
   float acc = 0.f;
   if (j < n) {
     const float *p = a.seg[s].slab + j;
-    const int S = a.seg[s].S;
 #pragma unroll 4
     for (int k = q; k < S; k += 4)
       acc += p[(long)k * n];
@@ -784,12 +830,19 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(ReduceArgs a, float *
     G[a.seg[s].dst + j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *G) {
+  static const long wide_min = [] { // A/B switch: smallest segment that takes the 16-byte path
+    const char *e = getenv("ALEPPO_REDUCE_WIDE_MIN");
+    return e ? atol(e) : 1L << 18;
+  }();
   ReduceArgs a;
   a.nseg = nseg;
   a.cprefix[0] = 0;
   for (int i = 0; i < nseg; ++i) {
     a.seg[i] = segs[i];
-    a.cprefix[i + 1] = a.cprefix[i] + (int)((segs[i].n + 63) / 64);
+    const bool aligned = segs[i].n % 4 == 0 && segs[i].dst % 4 == 0 && ((uintptr_t)segs[i].slab & 15) == 0 &&
+                         ((uintptr_t)G & 15) == 0;
+    a.wide[i] = aligned && segs[i].n >= wide_min;
+    a.cprefix[i + 1] = a.cprefix[i] + (int)(a.wide[i] ? (segs[i].n + 1023) / 1024 : (segs[i].n + 63) / 64);
   }
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(a.cprefix[nseg]), dim3(256), 0, s, a, G);
 }

@@ -326,6 +326,39 @@ def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M, H):
         np.testing.assert_allclose(m1["grad_norm"], w["grad_norm"], rtol=5e-2)
 
 
+def test_full_size_update_is_deterministic_and_schedule_independent(pkg):
+    """BASELINE configs[1] update shape (128 envs x T=128 -> 16384 samples, 4 minibatches of 4096, H=512, bf16): the
+    update's kernels do not depend on how they are scheduled.  The timed schedule runs the weight-gradient kernels and
+    the slab reduce on a second stream beside the dgrad chain; ALEPPO_OPT_SERIAL_UPDATE runs every kernel on one stream.
+    Every reduction has a fixed order (no atomics), so the two schedules - and a repeat of the first - must leave
+    bit-identical parameters, Adam moments and metrics after two epochs; a missing stream dependency shows up here."""
+    E, T, A, H, M = 128, 128, 4, 512, 4
+    N = E * T
+    params = hf.fill_params(940, H, A)
+    base = hf.hf_bytes(941, (N // 8, 4, 84, 84))  # 8 distinct byte-permuted copies: cheap to generate
+    obs = np.concatenate([base ^ np.uint8(31 * k) for k in range(8)])
+    actions = (hf.hf_u32(942, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(943, (N, A), -1, 1))
+    adv, ret = hf.hf_range(944, (N,), -1, 1), hf.hf_range(945, (N,), -1, 1)
+    masks = (hf.hf_unit(946, N) >= np.float32(0.05)).astype(np.uint8)
+    outs = []
+    for serial in (0, 1, 0):
+        eng = pkg.Engine(E, T, A, H, precision=pkg.BF16)
+        pkg.lib().aleppo_set_option(eng._ctx, pkg.OPT_SERIAL_UPDATE, serial)
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 2, M)
+        sd = eng.state_dict()
+        outs.append((m, eng.export_params(), sd["exp_avg"].copy(), sd["exp_avg_sq"].copy()))
+        eng.close()
+    assert np.isfinite(outs[0][0]["loss"]).all() and np.abs(outs[0][1] - params).max() > 0
+    for other in outs[1:]:
+        for k in ("loss", "grad_norm"):
+            np.testing.assert_array_equal(other[0][k], outs[0][0][k])
+        for a, b in zip(other[1:], outs[0][1:]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_replay_rollout_equals_the_manual_slot_loop(pkg):
     """aleppo_replay_rollout (the native T-slot act/step loop over a recorded trace) leaves exactly the rollout the
     per-slot calls leave: same built-in RNG stream, same observations, scalars, actions and values"""
