@@ -143,6 +143,27 @@ def test_sampling_g5_bit_exact(pkg, golden, A):
                                   golden[s + "actions"])
 
 
+@pytest.mark.parametrize("A", [1, 9, 18])
+def test_sampling_and_losses_wide_action_sets_vs_oracle(pkg, A):
+    """The reference's golden vectors hold A = 4 and 6 (Breakout, Pong); the full ALE action set has 18 and takes the
+    third instantiation of the head kernels.  Same checks against the pinned oracle: sampled indices bit-exact, loss
+    terms and gradients to 1e-5 / 1e-6.  A = 1 is the degenerate single-action policy."""
+    E, B = 333, 200
+    probs = orc.softmax(hf.hf_range(960 + A, (E, A), -3, 3))
+    q = np.maximum(hf.hf_unit(961 + A, (E, A)), np.float32(1e-7))
+    np.testing.assert_array_equal(pkg.sampling.multinomial_with_noise(probs, q), orc.sample(probs, q))
+    logits = hf.hf_range(962 + A, (B, A), -2, 2)
+    actions = (hf.hf_u32(963 + A, B) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(964 + A, (B, A), -2, 2))
+    adv, val, ret = hf.hf_range(965, (B,), -2, 2), hf.hf_range(966, (B,), -1, 1), hf.hf_range(967, (B,), -1.5, 1.5)
+    masks = (hf.hf_unit(968, B) >= np.float32(0.05)).astype(np.uint8)
+    o = pkg.losses.compute(logits, old_lp, actions, adv, val, ret, masks, 0.1, 0.5, 0.01)
+    w = orc.ppo_loss(logits, old_lp, actions, adv, val, ret, masks, 0.1, 0.5, 0.01)
+    np.testing.assert_allclose(o.loss[0], w["loss"], atol=1e-5)
+    np.testing.assert_allclose(o.dlogits, w["dlogits"], atol=1e-6)
+    np.testing.assert_allclose(o.dvalues, w["dvalues"], atol=1e-7)
+
+
 # ------------------------------------------------------------------ network forward
 @pytest.mark.parametrize("H,A", [(32, 4), (32, 6), (512, 4), (512, 6)])
 def test_forward_g3_fp32(pkg, golden, H, A):
@@ -219,7 +240,8 @@ def test_train_g4_fp32(pkg, golden, name, epochs, M):
     eng.close()
 
 
-@pytest.mark.parametrize("prec,H,A,N,M", [("fp32", 512, 6, 96, 2), ("fp32", 64, 4, 40, 1), ("bf16", 512, 4, 96, 2)])
+@pytest.mark.parametrize("prec,H,A,N,M", [("fp32", 512, 6, 96, 2), ("fp32", 64, 4, 40, 1), ("bf16", 512, 4, 96, 2),
+                                          ("fp32", 64, 18, 40, 1), ("fp32", 512, 9, 96, 2), ("bf16", 512, 18, 96, 2)])
 def test_train_vs_oracle(pkg, prec, H, A, N, M):
     params = hf.fill_params(510, H, A)
     obs = hf.hf_bytes(511, (N, 4, 84, 84))
