@@ -787,7 +787,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         *sBh = c->slab + c->slab_off[9];
   const size_t fs = c->metric_cap; // field stride of the per-sample metric arrays
   const int nblk_head = (int)std::min<long>(MAXS_HEAD, (B + 15) / 16);
-  const int nblk_sq = (int)std::min<size_t>(1024, (L.total() + 4095) / 4096);
+  const int nblk_sq = (int)std::min<size_t>(800, (L.off[P_W1] + 4095) / 4096); // + 129 conv1 chunks <= 1024 partials
 
   // The three weight-gradient kernels (and the slab reduce of bucket 0) run on their own stream
   // next to the dgrad chain (fc wgrad || fc dgrad, conv3 wgrad || conv3 dgrad, conv2 wgrad || conv2 dgrad -> conv1
@@ -892,11 +892,23 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         HIPCHK(c, hipEventRecord(c->ev_wg, sw));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_wg, 0));
       }
-      prof_begin(c, ALEPPO_K_REDUCE);
-      segs[nseg++] = ReduceSeg{sW1, S1, 32 * 256, (long)L.off[P_W1]};
-      segs[nseg++] = ReduceSeg{sB1, S1, 32, (long)L.off[P_B1]};
-      launch_reduce_slabs(s, segs, nseg, c->G);
-      prof_end(c, ALEPPO_K_REDUCE);
+      // conv1's slabs: with data parallelism they are reduced now (the all-reduce needs the whole gradient); on one GPU
+      // the sum-of-squares pass below sums them on the fly - one launch less on the serial tail of the minibatch.
+      ReduceSeg tail[2] = {{sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
+      static const bool fuse_tail = [] { // A/B switch
+        const char *e = getenv("ALEPPO_FUSE_TAIL_REDUCE");
+        return !e || atoi(e) != 0;
+      }();
+      if (dp || !fuse_tail) {
+        segs[nseg++] = tail[0];
+        segs[nseg++] = tail[1];
+        tail[0].slab = tail[1].slab = nullptr;
+      }
+      if (nseg) {
+        prof_begin(c, ALEPPO_K_REDUCE);
+        launch_reduce_slabs(s, segs, nseg, c->G);
+        prof_end(c, ALEPPO_K_REDUCE);
+      }
       if (dp) {
         HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
@@ -907,12 +919,13 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_comm1, 0));
       }
       prof_begin(c, ALEPPO_K_ADAM);
-      launch_sumsq(s, c->G, (long)L.total(), c->sumsq_part, nblk_sq);
+      // (pads between tensors are zero: only [0, off[P_W1]) and the two conv1 tensors contribute)
+      const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail);
       c->adam_step += 1;
       const double b1 = c->cfg.adam_beta1, b2 = c->cfg.adam_beta2;
       const double bc1 = 1.0 - std::pow(b1, (double)c->adam_step), bc2 = 1.0 - std::pow(b2, (double)c->adam_step);
       launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, prec, (long)L.total(),
-                  c->sumsq_part, nblk_sq, hp.max_norm, (float)(lr / bc1), (float)std::sqrt(bc2), (float)b1, (float)b2,
+                  c->sumsq_part, nblk_norm, hp.max_norm, (float)(lr / bc1), (float)std::sqrt(bc2), (float)b1, (float)b2,
                   c->cfg.adam_eps, c->grad_norms + mi);
       prof_end(c, ALEPPO_K_ADAM);
       // The dgrad weight layouts (W2d, W3d, WfcT) are first needed by the NEXT minibatch's fc dgrad: repack them

@@ -172,7 +172,9 @@ struct ReduceSeg {
   long dst;
 };
 void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *G);
-void launch_sumsq(hipStream_t s, const float *G, long n, float *partials, int nblk);
+// squares G[0, n_main) in nblk_main blocks + the two tail tensors (slab sums fused when tail[i].slab != nullptr);
+// returns the number of partials written (<= 1024)
+int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2]);
 void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
                  int prec, long n, const float *partials, int nblk, float max_norm, float step_size, float bc2_sqrt,
                  float beta1, float beta2, float eps, float *grad_norm_out);

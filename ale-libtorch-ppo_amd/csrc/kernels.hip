@@ -853,19 +853,66 @@ void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *
 // (identical norm everywhere), scales by min(1, max_norm/(norm+1e-6)) and applies the update.  The
 // bf16 compute copy of the weights is refreshed in the same pass.
 // ================================================================================================
-__global__ __launch_bounds__(256) void sumsq_kernel(const float *__restrict__ G, long n, float *partials) {
+// Blocks [0, nmain) square G[0, n).  The blocks after them own the LAST gradient tensors (conv1 weight + bias, 64
+// outputs per block) and either sum their split-K slabs first - the update's last slab reduce fused into this pass, one
+// launch less on the serial tail of every minibatch - or, when the slabs were reduced before (data parallelism: the
+// all-reduce needs G complete), read G.  Same partition and same summation order in both modes: identical partials.
+struct SumsqTail {
+  ReduceSeg seg[2]; // slab == nullptr: the tensor is already in G
+  int chunks[2];    // 64-output chunks per tensor
+};
+__global__ __launch_bounds__(256) void sumsq_kernel(float *__restrict__ G, long n, float *partials, int nmain,
+                                                    SumsqTail tail) {
   __shared__ float s4[4];
-  const long per = (n + gridDim.x - 1) / gridDim.x;
-  const long b = (long)blockIdx.x * per, e = min(n, b + per);
+  __shared__ float part[4][64];
   float s = 0.f;
-  for (long i = b + threadIdx.x; i < e; i += 256)
-    s += G[i] * G[i];
+  if ((int)blockIdx.x < nmain) {
+    const long per = (n + nmain - 1) / nmain;
+    const long b = (long)blockIdx.x * per, e = min(n, b + per);
+    for (long i = b + threadIdx.x; i < e; i += 256)
+      s += G[i] * G[i];
+  } else {
+    int c = (int)blockIdx.x - nmain, t = 0;
+    if (c >= tail.chunks[0]) {
+      c -= tail.chunks[0];
+      t = 1;
+    }
+    const ReduceSeg sg = tail.seg[t];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long j = (long)c * 64 + o;
+    float g = 0.f;
+    if (sg.slab) { // workgroup-uniform; same order as reduce_slabs_kernel's narrow path
+      float acc = 0.f;
+      if (j < sg.n) {
+        const float *p = sg.slab + j;
+#pragma unroll 4
+        for (int k = q; k < sg.S; k += 4)
+          acc += p[(long)k * sg.n];
+      }
+      part[q][o] = acc;
+      __syncthreads();
+      if (q == 0 && j < sg.n) {
+        g = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+        G[sg.dst + j] = g;
+      }
+    } else if (q == 0 && j < sg.n) {
+      g = G[sg.dst + j];
+    }
+    s = g * g;
+  }
   s = block_sum_256(s, s4);
   if (threadIdx.x == 0)
     partials[blockIdx.x] = s;
 }
-void launch_sumsq(hipStream_t s, const float *G, long n, float *partials, int nblk) {
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, G, n, partials);
+int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2]) {
+  SumsqTail t;
+  for (int i = 0; i < 2; ++i) {
+    t.seg[i] = tail[i];
+    t.chunks[i] = (int)((tail[i].n + 63) / 64);
+  }
+  const int nblk = nblk_main + t.chunks[0] + t.chunks[1];
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, G, n_main, partials, nblk_main, t);
+  return nblk; // partials written
 }
 
 template <class T>
