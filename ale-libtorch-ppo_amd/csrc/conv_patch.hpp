@@ -695,7 +695,6 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   constexpr int XV = L::SB * PATCH * (int)sizeof(InT) / 16, NXV = (XV + 511) / 512;
   constexpr int DV = KPIX * L::OC / 8, NDV = (DV + 511) / 512; // dY source vectors (8 bf16)
   constexpr int VPR = L::OC / 8;                  // dY vectors per pixel row
-  constexpr int WN = 8 / L::WM;
   constexpr int SEG = L::KW * L::C;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16 *sbuf = reinterpret_cast<bf16 *>(smem);
