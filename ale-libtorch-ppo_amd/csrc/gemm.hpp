@@ -522,14 +522,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
   // Workgroups are dealt round-robin to the 8 XCDs in linear block order.  The gridDim.x m-tiles that share one
   // (n-tile, slice) B stream would land on 8 different L2s and each fetch it again (PMC: 211 MB fetched for 30 MB
   // of fc wgrad operands); with xcd_swizzle every XCD takes a CONTIGUOUS chunk of the work list instead, so
-  // those m-tiles run side by side on one XCD.  (Needs a block count that is a multiple of 8.)
+  // those m-tiles run side by side on one XCD.  (Needs a block count that is a multiple of 8; launched 1-D.)
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (xcd_swizzle) {
-    const int lin = bx + gridDim.x * (by + gridDim.y * bz), per = (gridDim.x * gridDim.y * gridDim.z) / 8;
+  if (xcd_swizzle) { // 1-D launch (blockIdx.x IS the dispatch order); xcd_swizzle = m-tiles | n-tiles << 12
+    const int gx = xcd_swizzle & 4095, gy = xcd_swizzle >> 12;
+    const int lin = blockIdx.x, per = gridDim.x / 8;
     const int w = (lin % 8) * per + lin / 8;
-    bx = w % gridDim.x;
-    by = (w / gridDim.x) % gridDim.y;
-    bz = w / (gridDim.x * gridDim.y);
+    bx = w % gx;
+    by = (w / gx) % gy;
+    bz = w / (gx * gy);
   }
   const int m0 = bx * BM, n0 = by * BN, z = bz;
   const int kbeg = z * kchunk, kend = min(Ktot, kbeg + kchunk);
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
         for (int j = 0; j < NI; ++j)
           AT::mma(fa[i], fb[j], acc[i][j]);
     }
-    if (BIAS && blockIdx.y == 0 && tid < BM) {
+    if (BIAS && by == 0 && tid < BM) { // (the LOGICAL n-tile 0: exactly one block per (m-tile, slice))
       float s = 0.f;
 #pragma unroll 8
       for (int p = 0; p < KP; ++p)
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(typename AL::P ap, typenam
         }
       }
     }
-  if (BIAS && blockIdx.y == 0 && tid < BM && m0 + tid < M)
+  if (BIAS && by == 0 && tid < BM && m0 + tid < M)
     bias_slab[(long)z * M + m0 + tid] = bsum;
 }
 

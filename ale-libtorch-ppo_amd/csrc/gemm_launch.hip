@@ -337,21 +337,22 @@ template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const vo
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
   // contiguous per-XCD work chunks (the m-tiles sharing an a3 stream on one L2) when the block count allows
-  auto swz = [&](const dim3 &g) { return ((g.x * g.y * S) % 8 == 0 && tune("ALEPPO_TN_XCD", 1)) ? 1 : 0; };
+  auto swz = [&](const dim3 &g) { return ((g.x * g.y * S) % 8 == 0 && tune("ALEPPO_TN_XCD", 1)) ? (int)(g.x | (g.y << 12)) : 0; };
+  auto grid = [&](const dim3 &g, int xsw) { return xsw ? dim3(g.x * g.y * S) : dim3(g.x, g.y, S); };
   if (v == 1) {
     const dim3 g = grid2(H, 64, FC_IN, 64);
     const int xsw = swz(g);
-    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp, sw,
+    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 64, 2, 2, true>), grid(g, xsw), dim3(256), 0, s, ap, bp, sw,
                        sb, H, FC_IN, (int)ns, kc, 1.0f, xsw);
   } else if (v == 2) {
     const dim3 g = grid2(H, 128, FC_IN, 64);
     const int xsw = swz(g);
-    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 128, 64, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp,
+    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 128, 64, 2, 2, true>), grid(g, xsw), dim3(256), 0, s, ap, bp,
                        sw, sb, H, FC_IN, (int)ns, kc, 1.0f, xsw);
   } else {
     const dim3 g = grid2(H, 64, FC_IN, 128);
     const int xsw = swz(g);
-    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), dim3(g.x, g.y, S), dim3(256), 0, s, ap, bp,
+    hipLaunchKernelGGL((gemm_tn_kernel<T, AL, BL, 64, 128, 2, 2, true>), grid(g, xsw), dim3(256), 0, s, ap, bp,
                        sw, sb, H, FC_IN, (int)ns, kc, 1.0f, xsw);
   }
   return S;
