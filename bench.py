@@ -169,7 +169,7 @@ def run(args):
     # one rollout (acting shapes) and one update (training shapes) are profiled separately
     roofline = None
     phase = {}
-    if rank == 0:
+    if True:  # EVERY rank runs the profiled passes (finish_rollout / train hold collectives); rank 0 reports
         def rollout_only():
             rew, te, tr, st = plans[-1]
             ra, ta, ua, sa = rew.ctypes.data, te.ctypes.data, tr.ctypes.data, st.ctypes.data
