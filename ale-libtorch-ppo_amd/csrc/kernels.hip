@@ -297,6 +297,16 @@ __device__ __forceinline__ float gae_step(float r, float v, float nv, float last
   return a;
 }
 
+// One thread = one environment, scanning t = T-1 .. 0.  The scan itself is a short dependent chain; what costs is
+// memory latency, so the inputs of 16 time steps are loaded together and the NEXT 16 are already in flight (second
+// register set) while a chunk is processed.  A chunk is processed branch-free (all 16 steps valid, the flag check
+// accumulates into a register): with per-step branches the compiler sinks every load into its step's block and each
+// step then pays a full memory round trip behind the previous step's scattered stores (54 us for T = 128).
+struct GaeChunk {
+  static constexpr int CH = 16;
+  float r[CH], v[CH];
+  uint8_t te[CH], tr[CH], st[CH];
+};
 __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const float *__restrict__ values_tm,
                                                   const float *__restrict__ logits_tm, const int *__restrict__ actions_tm,
                                                   float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
@@ -309,43 +319,67 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
   (void)oldlp_n;
   (void)act_n;
   (void)A;
+  constexpr int CH = GaeChunk::CH;
   const float gl = gamma * lambda;
   float last = 0.f, nv = values_tm[(size_t)T * E + e];
-  constexpr int CH = 16; // time steps whose (independent) loads are issued together before the serial chain
-  for (int t1 = T; t1 > 0; t1 -= CH) {
-    const int t0 = max(t1 - CH, 0);
-    float r[CH], v[CH];
-    uint8_t te[CH], tr[CH], st[CH];
+  int bad = 0;
+  auto step = [&](int t, float r, float v, bool bte, bool btr, bool bst) {
+    const float rc = fminf(fmaxf(r, -1.0f), 1.0f); // buffer.cc:67 clamp_, in place
+    reinterpret_cast<float *>(rec + (size_t)t * rb)[e] = rc;
+    bad |= ((int)bte + (int)btr + (int)bst > 1) ? 1 : 0; // gae.cc:49-53
+    const float a = gae_step(rc, v, nv, last, gamma, gl, bst, bte, btr);
+    const size_t n = (size_t)e * T + t;
+    adv_n[n] = a;
+    ret_n[n] = a + v;        // buffer.cc:70-71
+    mask_n[n] = bst ? 0 : 1; // buffer.cc:74
+    last = a;
+    nv = v;
+  };
+  auto load = [&](GaeChunk &c, int t1) { // steps t1-1 .. t1-CH, all valid
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       const int t = t1 - 1 - k;
-      const bool ok = t >= t0;
-      const uint8_t *fl = rec + (size_t)(ok ? t : t0) * rb + 4 * (size_t)E;
-      r[k] = ok ? reinterpret_cast<const float *>(rec + (size_t)t * rb)[e] : 0.f;
-      v[k] = ok ? values_tm[(size_t)t * E + e] : 0.f;
-      te[k] = ok ? fl[e] : 0;
-      tr[k] = ok ? fl[E + e] : 0;
-      st[k] = ok ? fl[2 * E + e] : 0;
+      const uint8_t *fl = rec + (size_t)t * rb + 4 * (size_t)E;
+      c.r[k] = reinterpret_cast<const float *>(rec + (size_t)t * rb)[e];
+      c.v[k] = values_tm[(size_t)t * E + e];
+      c.te[k] = fl[e];
+      c.tr[k] = fl[E + e];
+      c.st[k] = fl[2 * E + e];
     }
+  };
+  auto process = [&](const GaeChunk &c, int t1) {
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      const int t = t1 - 1 - k;
-      if (t < t0)
+    for (int k = 0; k < CH; ++k)
+      step(t1 - 1 - k, c.r[k], c.v[k], c.te[k] != 0, c.tr[k] != 0, c.st[k] != 0);
+  };
+  int t1 = T;
+  for (int rem = T % CH; rem > 0; --rem) { // the ragged top of the horizon, one step at a time
+    const int t = --t1;
+    const uint8_t *fl = rec + (size_t)t * rb + 4 * (size_t)E;
+    step(t, reinterpret_cast<const float *>(rec + (size_t)t * rb)[e], values_tm[(size_t)t * E + e], fl[e] != 0,
+         fl[E + e] != 0, fl[2 * E + e] != 0);
+  }
+  if (t1 > 0) { // t1 is a multiple of CH (uniform control flow: T is a kernel argument)
+    GaeChunk ca, cb;
+    load(ca, t1);
+    while (true) {
+      const bool more_b = t1 - CH > 0;
+      if (more_b)
+        load(cb, t1 - CH);
+      process(ca, t1);
+      if (!more_b)
         break;
-      const float rc = fminf(fmaxf(r[k], -1.0f), 1.0f); // buffer.cc:67 clamp_, in place
-      reinterpret_cast<float *>(rec + (size_t)t * rb)[e] = rc;
-      const bool bte = te[k] != 0, btr = tr[k] != 0, bst = st[k] != 0;
-      if ((int)bte + (int)btr + (int)bst > 1)
-        *err = 1; // gae.cc:49-53
-      const float a = gae_step(rc, v[k], nv, last, gamma, gl, bst, bte, btr);
-      const size_t n = (size_t)e * T + t;
-      adv_n[n] = a;
-      ret_n[n] = a + v[k];     // buffer.cc:70-71
-      mask_n[n] = bst ? 0 : 1; // buffer.cc:74
-      last = a;
-      nv = v[k];
+      const bool more_a = t1 - 2 * CH > 0;
+      if (more_a)
+        load(ca, t1 - 2 * CH);
+      process(cb, t1 - CH);
+      if (!more_a)
+        break;
+      t1 -= 2 * CH;
     }
   }
+  if (bad)
+    *err = 1;
 }
 // the embarrassingly parallel part of prepare_batch (train.cc:272-283): old log-probs + actions, one thread
 // per (t, e) slot, written env-major
