@@ -493,15 +493,17 @@ void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long
 // workgroup writes ONE partial slab of head-weight gradients (summed later in fixed order).
 // 1/N_m uses the GLOBAL unmasked count so that an all-reduce SUM over ranks yields the mean (8e).
 // ================================================================================================
+// Wide action sets (AMAX = 18: 19 x 8 wgrad accumulators per lane) run 4 waves per workgroup: one wave per SIMD may
+// use the whole 512-entry register file; with 8 waves the 256-register cap spilled the accumulators (150 us vs 22).
 template <class T, int AMAX>
-__global__ __launch_bounds__(512) void head_train_kernel(
+__global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
     const float *__restrict__ h, const float *__restrict__ Wh, const float *__restrict__ bh,
     const int *__restrict__ act, const float *__restrict__ oldlp, const float *__restrict__ adv,
     const float *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
     T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
     float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc) {
   constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
-  constexpr int NWV = 8;                // waves per workgroup
+  constexpr int NWV = AMAX > 10 ? 4 : 8; // waves per workgroup
   extern __shared__ float smem[];
   float *sW = smem;                    // [(A+1)][H]
   float *sAcc = smem + (size_t)A1 * H; // [(A+1)][H] cross-wave wgrad accumulator
@@ -761,7 +763,7 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
     if (sm > 48 * 1024)                                                                                                \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&head_train_kernel<T, AM>),                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
-    hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(512), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
+    hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(AM > 10 ? 256 : 512), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
                        mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
                        ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts, slab_bfc);                                         \
   } while (0)
@@ -769,6 +771,8 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
     LAUNCH_HEAD(4);
   else if (A <= 6)
     LAUNCH_HEAD(6);
+  else if (A <= 10)
+    LAUNCH_HEAD(10);
   else
     LAUNCH_HEAD(18);
 #undef LAUNCH_HEAD
