@@ -563,6 +563,48 @@ def test_rccl_path_with_one_rank_communicator(pkg, prec):
     np.testing.assert_array_equal(out[0][1], out[1][1])
 
 
+def test_rccl_communicator_beside_torch_distributed_nccl(tmp_path):
+    """bench.py's multi-GPU situation in one process: torch.distributed's NCCL (= RCCL) process group for the barriers /
+    timing reductions AND the library's own RCCL communicator for the gradient all-reduce.  One rank (one GPU on this
+    box), in a subprocess so that the process group does not leak into the other tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "coexist.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import hashfill as hf
+from __graft_entry__ import load_package
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+pkg = load_package()
+uid = [pkg.Engine.comm_unique_id()]
+dist.broadcast_object_list(uid, src=0)
+H, A, N, M = 64, 4, 64, 2
+eng = pkg.Engine(8, 8, A, H, precision=pkg.BF16, advantage_norm=False)
+eng.comm_init(uid[0])
+eng._c(pkg.lib().aleppo_set_option(eng._ctx, pkg.OPT_FORCE_COMM, 1))
+eng.load_params(hf.fill_params(910, H, A))
+rng = np.random.default_rng(0)
+eng.set_batch(rng.integers(0, 256, (N, 4, 84, 84), dtype=np.uint8), rng.integers(0, A, N),
+              np.full((N, A), -np.log(A), np.float32), rng.standard_normal(N).astype(np.float32),
+              rng.standard_normal(N).astype(np.float32), np.ones(N, np.uint8))
+t = torch.ones(1, device="cuda")
+dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
+m = eng.train(2.5e-4, 2, M)
+dist.all_reduce(t); dist.barrier(); torch.cuda.synchronize()
+assert np.isfinite(m["loss"]).all() and t.item() == 1.0
+eng.close()
+dist.destroy_process_group()
+print("COEXIST_OK")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "COEXIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_checkpoint_resume_is_bit_identical(pkg):
     H, A, N, M = 64, 4, 64, 2
     params = hf.fill_params(930, H, A)
