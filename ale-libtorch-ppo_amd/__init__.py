@@ -27,9 +27,10 @@ LIB_PATH = os.path.join(_HERE, "libaleppo.so")
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4
 FP32, BF16 = 0, 1
-HOST, DEVICE = 0, 1
+HOST, DEVICE, HOST_MAPPED = 0, 1, 2
 FRAMES_84, FRAMES_RAW_PAIR = 0, 1
-ABI_VERSION = 1
+ROLLOUT_FP32, ROLLOUT_FP16 = 0, 1
+ABI_VERSION = 2
 UNIQUE_ID_BYTES = 128
 
 FIELDS = dict(observations=0, actions=1, rewards=2, masks=3, logits=4, values=5, advantages=6, returns=7,
@@ -42,6 +43,7 @@ KERNEL_CLASSES = dict(ingest=0, gae=1, head=2, adam=3, conv1_fwd=4, conv2_fwd=5,
 # every symbol include/aleppo.h declares (checked by tests/test_abi.py against the header text)
 # aleppo_set_option keys (include/aleppo.h)
 OPT_GENERIC_CONV, OPT_DEBUG_NO_PUBLISH, OPT_FORCE_COMM, OPT_SERIAL_UPDATE = 0, 1, 2, 3
+OPT_FC_PIPE, OPT_FC_PIPE_WGRAD, OPT_FUSED_ACT, OPT_UPDATE_GRAPH = 4, 5, 6, 7
 
 EXPORTS = [
     "aleppo_abi_version", "aleppo_create", "aleppo_destroy", "aleppo_last_error", "aleppo_param_count",
@@ -67,7 +69,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device_ordinal", C.c_int32), ("world_size", C.c_int32),
                 ("rank", C.c_int32), ("num_envs", C.c_int32), ("horizon", C.c_int32), ("num_actions", C.c_int32),
                 ("hidden_size", C.c_int32), ("frame_stack", C.c_int32), ("precision", C.c_int32),
-                ("advantage_norm", C.c_int32), ("max_minibatch", C.c_int32), ("gamma", C.c_float),
+                ("advantage_norm", C.c_int32), ("max_minibatch", C.c_int32), ("rollout_precision", C.c_int32),
+                ("gamma", C.c_float),
                 ("lambda_", C.c_float), ("clip_param", C.c_float), ("value_loss_coef", C.c_float),
                 ("entropy_coef", C.c_float), ("max_gradient_norm", C.c_float), ("adam_beta1", C.c_float),
                 ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("seed", C.c_uint64)]
@@ -236,10 +239,10 @@ class Engine:
 
     def __init__(self, num_envs, horizon, num_actions=4, hidden_size=512, precision=FP32, gamma=0.99, lam=0.95,
                  clip_param=0.1, value_loss_coef=0.5, entropy_coef=0.01, max_gradient_norm=0.5, device=0,
-                 world_size=1, rank=0, seed=42, advantage_norm=False, max_minibatch=0):
+                 world_size=1, rank=0, seed=42, advantage_norm=False, max_minibatch=0, rollout_precision=ROLLOUT_FP32):
         self.cfg = Config(ABI_VERSION, device, world_size, rank, num_envs, horizon, num_actions, hidden_size, 4,
-                          precision, int(advantage_norm), max_minibatch, gamma, lam, clip_param, value_loss_coef,
-                          entropy_coef, max_gradient_norm, 0.0, 0.0, 0.0, seed)
+                          precision, int(advantage_norm), max_minibatch, rollout_precision, gamma, lam, clip_param,
+                          value_loss_coef, entropy_coef, max_gradient_norm, 0.0, 0.0, 0.0, seed)
         self._ctx = C.c_void_p()
         _check(lib().aleppo_create(C.byref(self.cfg), C.byref(self._ctx)))
         self.E, self.T, self.A, self.H = num_envs, horizon, num_actions, hidden_size
@@ -331,14 +334,22 @@ class Engine:
         if rc:
             self._c(rc)
 
-    def replay_rollout(self, frames_addr, kind, slot_stride_bytes, rewards, terminated, truncated, episode_start):
-        """aleppo_replay_rollout: the T-slot act/step loop over a recorded trace (device frames, host [T][E] scalars)"""
+    def replay_rollout(self, frames_addr, kind, slot_stride_bytes, rewards, terminated, truncated, episode_start,
+                       noise=None, location=DEVICE):
+        """aleppo_replay_rollout: the T-slot act/step loop over a recorded trace (frames in device or mapped
+        page-locked host memory, host [T][E] scalars, optional [T][E][A] sampling noise)"""
         r, te, tr, st = _f32(rewards), _u8(terminated), _u8(truncated), _u8(episode_start)
         for a in (r, te, tr, st):
             if a.shape != (self.T, self.E):
                 raise AleppoInvalidArgument("replay_rollout: scalars must be [T][E]")
-        self._c(lib().aleppo_replay_rollout(self._ctx, C.c_void_p(frames_addr), int(kind),
-                                            C.c_size_t(slot_stride_bytes), _ptr(r), _ptr(te), _ptr(tr), _ptr(st)))
+        nz = None
+        if noise is not None:
+            nz = _f32(noise)
+            if nz.shape != (self.T, self.E, self.A):
+                raise AleppoInvalidArgument("replay_rollout: noise must be [T][E][A]")
+        self._c(lib().aleppo_replay_rollout(self._ctx, C.c_void_p(frames_addr), int(kind), int(location),
+                                            C.c_size_t(slot_stride_bytes), _ptr(r), _ptr(te), _ptr(tr), _ptr(st),
+                                            _ptr(nz)))
 
     def set_gray_lut(self, lut):
         self._c(lib().aleppo_set_gray_lut(self._ctx, _ptr(_u8(lut))))
@@ -410,9 +421,13 @@ class Engine:
         self._c(lib().aleppo_profile_read(self._ctx, KERNEL_CLASSES[name], C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def set_option(self, option, value):
+        """aleppo_set_option: per-context A/B switches (OPT_*)"""
+        self._c(lib().aleppo_set_option(self._ctx, int(option), int(value)))
+
     def set_generic_conv(self, on):
-        """A/B switch: run bf16 convolutions on the generic gather-GEMM kernels (process-wide)."""
-        self._c(lib().aleppo_set_option(self._ctx, 0, int(on)))
+        """A/B switch: run bf16 convolutions on the generic gather-GEMM kernels (this context only)."""
+        self.set_option(OPT_GENERIC_CONV, on)
 
     def synchronize(self):
         self._c(lib().aleppo_synchronize(self._ctx))

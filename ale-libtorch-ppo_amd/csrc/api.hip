@@ -21,6 +21,26 @@ int set_err(Ctx *c, int code, const std::string &msg) {
   return code;
 }
 
+// ------------------------------------------------------------------ per-context kernel-selection switches
+static thread_local const Tuning *g_tuning = nullptr;
+Tuning tuning_from_env() { // read once per context, in aleppo_create
+  auto flag = [](const char *name, bool dflt) {
+    const char *e = std::getenv(name);
+    return e ? std::atoi(e) != 0 : dflt;
+  };
+  Tuning t;
+  t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
+  t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
+  t.fc_pipe_wgrad = flag("ALEPPO_FC_PIPE_WGRAD", false);
+  t.fused_act = flag("ALEPPO_FUSED_ACT", true);
+  return t;
+}
+const Tuning &tuning() {
+  static const Tuning dflt = tuning_from_env();
+  return g_tuning ? *g_tuning : dflt;
+}
+void set_tuning(const Tuning *t) { g_tuning = t; }
+
 // ------------------------------------------------------------------ parameter layout
 static inline size_t align64(size_t x) { return (x + 63) / 64 * 64; }
 void ParamLayout::init(int H_, int A_) {
@@ -115,9 +135,24 @@ void params_to_reference(const ParamLayout &L, const float *internal, float *ref
 } // namespace aleppo
 
 // ------------------------------------------------------------------ helpers
+// every stateful entry point: the caller's thread may have another device current, and the kernel-selection switches
+// are this context's
 #define CHECK_CTX(c)                                                                                                   \
-  if (!(c))                                                                                                            \
-  return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "null context")
+  do {                                                                                                                 \
+    if (!(c))                                                                                                          \
+      return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "null context");                                            \
+    if (hipSetDevice((c)->cfg.device_ordinal) != hipSuccess)                                                           \
+      return set_err(const_cast<aleppo_ctx *>(c), ALEPPO_ERR_HIP, "hipSetDevice failed");                              \
+    set_tuning(&(c)->tune);                                                                                            \
+  } while (0)
+#define CHECK_ASYNC(c)                                                                                                 \
+  do {                                                                                                                 \
+    if ((c)->async_err != hipSuccess) {                                                                                \
+      const hipError_t e_ = (c)->async_err;                                                                            \
+      (c)->async_err = hipSuccess;                                                                                     \
+      return set_err((c), ALEPPO_ERR_HIP, std::string("asynchronous HIP failure: ") + hipGetErrorString(e_));          \
+    }                                                                                                                  \
+  } while (0)
 #define NCCLCHK(c, x)                                                                                                  \
   do {                                                                                                                 \
     ncclResult_t r_ = (x);                                                                                             \
@@ -133,6 +168,12 @@ template <class T> static hipError_t dalloc(T **p, size_t bytes) {
   return e;
 }
 
+// a failure inside a helper that cannot return a status is kept in the context and reported by CHECK_ASYNC at the end of
+// the entry point (never dropped)
+static inline void note(Ctx *c, hipError_t e) {
+  if (e != hipSuccess && c->async_err == hipSuccess)
+    c->async_err = e;
+}
 static void prof_begin(Ctx *c, int cls, hipStream_t st = nullptr) {
   if (!c->prof_on)
     return;
@@ -140,13 +181,13 @@ static void prof_begin(Ctx *c, int cls, hipStream_t st = nullptr) {
     st = c->stream;
   ProfClass &p = c->prof[cls];
   if (p.used == p.start.size()) {
-    hipEvent_t a, b;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
+    hipEvent_t a = nullptr, b = nullptr;
+    note(c, hipEventCreate(&a));
+    note(c, hipEventCreate(&b));
     p.start.push_back(a);
     p.stop.push_back(b);
   }
-  hipEventRecord(p.start[p.used], st);
+  note(c, hipEventRecord(p.start[p.used], st));
 }
 static void prof_end(Ctx *c, int cls, hipStream_t st = nullptr) { // same stream as the matching prof_begin
   if (!c->prof_on)
@@ -154,7 +195,7 @@ static void prof_end(Ctx *c, int cls, hipStream_t st = nullptr) { // same stream
   if (!st)
     st = c->stream;
   ProfClass &p = c->prof[cls];
-  hipEventRecord(p.stop[p.used], st);
+  note(c, hipEventRecord(p.stop[p.used], st));
   p.used++;
 }
 
@@ -173,9 +214,9 @@ static const void *Pcw(const Ctx *c, ParamId id) {
 
 // conv stack forward for ns samples addressed by map -> c->h
 // returns the number of split-K partial slabs of h (1 unless max_parts allows the pipelined fc kernel to split)
-static int net_forward(Ctx *c, SampleMap map, long ns, int max_parts = 1) {
+static int net_forward(Ctx *c, const uint32_t *obs, SampleMap map, long ns, int max_parts = 1) {
   prof_begin(c, ALEPPO_K_CONV1_FWD);
-  conv1_fwd(c->stream, c->prec, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, ns);
+  conv1_fwd(c->stream, c->prec, obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, ns);
   prof_end(c, ALEPPO_K_CONV1_FWD);
   prof_begin(c, ALEPPO_K_CONV2_FWD);
   conv2_fwd(c->stream, c->prec, c->a1, Pcw(c, P_W2), Pf(c, P_B2), c->a2, ns);
@@ -240,12 +281,16 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "precision must be ALEPPO_FP32 or ALEPPO_BF16");
   if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad world_size / rank");
+  if (cfg->rollout_precision != ALEPPO_ROLLOUT_FP32 && cfg->rollout_precision != ALEPPO_ROLLOUT_FP16)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "rollout_precision must be ALEPPO_ROLLOUT_FP32 or _FP16");
   int rc = select_device(cfg->device_ordinal);
   if (rc)
     return rc;
 
   aleppo_ctx *c = new aleppo_ctx();
   c->cfg = *cfg;
+  c->tune = tuning_from_env();
+  set_tuning(&c->tune);
   if (c->cfg.adam_beta1 == 0.f)
     c->cfg.adam_beta1 = 0.9f;
   if (c->cfg.adam_beta2 == 0.f)
@@ -361,6 +406,8 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
 extern "C" void aleppo_destroy(aleppo_ctx *c) {
   if (!c)
     return;
+  set_tuning(nullptr);
+  (void)hipSetDevice(c->cfg.device_ordinal);
   hipDeviceSynchronize();
   if (c->nccl_comm)
     ncclCommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
@@ -369,7 +416,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
                  c->mask_n, c->mask_counts, c->P,    c->G,         c->Gs,         c->M1,      c->M2,
                  c->W2d,   c->W3d,      c->WfcT,      c->a1,        c->a2,         c->a3,      c->dz1,
                  c->dz2,   c->dz3,      c->h,         c->hpart,     c->dh,        c->logits_b,   c->values_b, c->slab,
-                 c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats};
+                 c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats, c->stage_u8, c->stage_obs};
   for (void *p : dev)
     if (p)
       hipFree(p);
@@ -563,6 +610,18 @@ static int upload_frames(aleppo_ctx *c, const uint8_t *frames, int kind, int loc
     *dev_frames = frames;
     return ALEPPO_OK;
   }
+  if (location == ALEPPO_HOST_MAPPED) { // the kernel reads the page-locked host buffer in place
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<uint8_t *>(frames), 0) != hipSuccess || !dp)
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT,
+                     "ALEPPO_HOST_MAPPED frames must lie in mapped page-locked host memory (hipHostMalloc / hipHostRegister)");
+    if (reinterpret_cast<uintptr_t>(dp) % 16)
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "mapped frames must be 16-byte aligned");
+    *dev_frames = static_cast<const uint8_t *>(dp);
+    return ALEPPO_OK;
+  }
+  if (location != ALEPPO_HOST)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown frame location");
   std::memcpy(c->h_frames, frames, bytes);
   HIPCHK(c, hipMemcpyAsync(c->d_frames, c->h_frames, bytes, hipMemcpyHostToDevice, c->stream));
   *dev_frames = c->d_frames;
@@ -660,20 +719,22 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
   c->t++;
   return ALEPPO_OK;
 }
-extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int kind, size_t slot_stride_bytes,
-                                     const float *rewards, const uint8_t *terminated, const uint8_t *truncated,
-                                     const uint8_t *episode_start) {
+extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int kind, int location,
+                                     size_t slot_stride_bytes, const float *rewards, const uint8_t *terminated,
+                                     const uint8_t *truncated, const uint8_t *episode_start, const float *noise) {
   CHECK_CTX(c);
   if (!frames || !rewards || !terminated || !truncated || !episode_start)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (location != ALEPPO_DEVICE && location != ALEPPO_HOST_MAPPED)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "replay_rollout: frames must be ALEPPO_DEVICE or ALEPPO_HOST_MAPPED");
   if (c->t != 0)
     return set_err(c, ALEPPO_ERR_RUNTIME, "replay_rollout needs an empty rollout buffer");
   const size_t E = (size_t)c->E;
   for (int t = 0; t < c->T; ++t) { // rollout.cc:198-278 with the emulator replaced by the recorded trace
-    int rc = aleppo_act(c, nullptr, nullptr);
+    int rc = aleppo_act(c, noise ? noise + (size_t)t * E * c->A : nullptr, nullptr);
     if (rc)
       return rc;
-    rc = aleppo_step(c, frames + (size_t)t * slot_stride_bytes, kind, ALEPPO_DEVICE, rewards + (size_t)t * E,
+    rc = aleppo_step(c, frames + (size_t)t * slot_stride_bytes, kind, location, rewards + (size_t)t * E,
                      terminated + (size_t)t * E, truncated + (size_t)t * E, episode_start + (size_t)t * E);
     if (rc)
       return rc;
@@ -793,17 +854,17 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   // next to the dgrad chain (fc wgrad || fc dgrad, conv3 wgrad || conv3 dgrad, conv2 wgrad || conv2 dgrad -> conv1
   // wgrad).  Every kernel is a latency-bound full-GPU persistent grid: co-scheduling fills the drain / ramp bubbles
   // between dependent launches.
-  static const bool two_env = [] {
+  static const bool two_env = [] { // process-wide A/B switch, read once
     const char *e = std::getenv("ALEPPO_BWD_STREAMS");
     return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
   const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
-  auto fork = [&](hipEvent_t ev) { // sw continues after everything enqueued on s so far
-    if (two) {
-      (void)hipEventRecord(ev, s);
-      (void)hipStreamWaitEvent(sw, ev, 0);
-    }
+  auto fork = [&](hipEvent_t ev) -> hipError_t { // sw continues after everything enqueued on s so far
+    if (!two)
+      return hipSuccess;
+    const hipError_t e = hipEventRecord(ev, s);
+    return e != hipSuccess ? e : hipStreamWaitEvent(sw, ev, 0);
   };
   bool pack_pending = false;
   for (int ep = 0; ep < epochs; ++ep)
@@ -811,7 +872,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const int mi = ep * M + mb;
       const long n0 = (long)mb * B;
       const SampleMap map = train_map(c, n0);
-      const int hparts = net_forward(c, map, B, FC_FWD_MAX_PARTS);
+      const int hparts = net_forward(c, c->obs, map, B, FC_FWD_MAX_PARTS);
       const bool wg_pipe = fc_wgrad_pipelined(prec, B, H); // then the head kernel also emits the fc bias gradient
       prof_begin(c, ALEPPO_K_HEAD);
       launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, c->oldlp_n + n0 * A, c->adv_n + n0,
@@ -825,7 +886,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
         pack_pending = false;
       }
-      fork(c->ev_head); // dh is ready
+      HIPCHK(c, fork(c->ev_head)); // dh is ready
       prof_begin(c, ALEPPO_K_FC_DGRAD);
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
       prof_end(c, ALEPPO_K_FC_DGRAD);
@@ -856,14 +917,14 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         NCCLCHK(c, ncclAllReduce(c->G, c->G, L.bucket0_end, ncclFloat, ncclSum, comm, c->comm_stream));
         HIPCHK(c, hipEventRecord(c->ev_comm0, c->comm_stream));
       }
-      fork(c->ev_dz3); // dz3 is ready
+      HIPCHK(c, fork(c->ev_dz3)); // dz3 is ready
       prof_begin(c, ALEPPO_K_CONV3_DGRAD);
       conv3_dgrad(s, prec, c->dz3, c->W3d, c->a2, c->dz2, B);
       prof_end(c, ALEPPO_K_CONV3_DGRAD);
       prof_begin(c, ALEPPO_K_CONV3_WGRAD, sw);
       const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
       prof_end(c, ALEPPO_K_CONV3_WGRAD, sw);
-      fork(c->ev_dz2); // dz2 is ready
+      HIPCHK(c, fork(c->ev_dz2)); // dz2 is ready
       prof_begin(c, ALEPPO_K_CONV2_DGRAD);
       conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
       prof_end(c, ALEPPO_K_CONV2_DGRAD);
@@ -946,6 +1007,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   HIPCHK(c, hipMemcpyAsync(c->h_metric_red, c->metric_red, (size_t)nm * 8 * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_metric_red + (size_t)nm * 8, c->grad_norms, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  CHECK_ASYNC(c);
   c->last_epochs = epochs;
   c->last_M = M;
   c->last_B = B;
@@ -974,6 +1036,21 @@ extern "C" int aleppo_read_train_metric(aleppo_ctx *c, int field, float *dst, si
   return ALEPPO_OK;
 }
 
+// NCHW uint8 observations of the caller -> c->stage_u8 (device), grown on demand and kept
+static int stage_observations(aleppo_ctx *c, const uint8_t *observations, int64_t n) {
+  const size_t bytes = (size_t)n * 4 * FRAME_PIX;
+  if (bytes > c->stage_u8_cap) {
+    if (c->stage_u8)
+      HIPCHK(c, hipFree(c->stage_u8));
+    c->stage_u8 = nullptr;
+    c->stage_u8_cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->stage_u8), bytes));
+    c->stage_u8_cap = bytes;
+  }
+  HIPCHK(c, hipMemcpy(c->stage_u8, observations, bytes, hipMemcpyHostToDevice));
+  return ALEPPO_OK;
+}
+
 extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, const int64_t *actions,
                                 const float *log_probabilities, const float *advantages, const float *returns,
                                 const uint8_t *masks, int64_t n) {
@@ -982,26 +1059,23 @@ extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, cons
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
   if (n <= 0 || n > c->N)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "set_batch: n must be in [1, E*T]");
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  uint8_t *tmp = nullptr;
-  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * 4 * FRAME_PIX));
-  HIPCHK(c, hipMemcpy(tmp, observations, (size_t)n * 4 * FRAME_PIX, hipMemcpyHostToDevice));
-  launch_obs_pack(c->stream, tmp, c->obs, n, train_map(c, 0));
   std::vector<int> a32(n);
   for (int64_t i = 0; i < n; ++i) {
-    if (actions[i] < 0 || actions[i] >= c->A) {
-      hipFree(tmp);
+    if (actions[i] < 0 || actions[i] >= c->A)
       return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "action index out of range");
-    }
     a32[i] = (int)actions[i];
   }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = stage_observations(c, observations, n);
+  if (rc)
+    return rc;
+  launch_obs_pack(c->stream, c->stage_u8, c->obs, n, train_map(c, 0));
   HIPCHK(c, hipMemcpy(c->act_n, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->oldlp_n, log_probabilities, (size_t)n * c->A * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->adv_n, advantages, (size_t)n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->ret_n, returns, (size_t)n * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->mask_n, masks, (size_t)n, hipMemcpyHostToDevice));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  hipFree(tmp);
   c->batch_n = n;
   return ALEPPO_OK;
 }
@@ -1010,19 +1084,30 @@ extern "C" int aleppo_forward(aleppo_ctx *c, const uint8_t *observations, int64_
   CHECK_CTX(c);
   if (!observations || !logits || !values)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
-  if (n <= 0 || n > c->maxB || n > c->N)
+  if (n <= 0 || n > c->maxB)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "forward: n exceeds capacity");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  uint8_t *tmp = nullptr;
-  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * 4 * FRAME_PIX));
-  HIPCHK(c, hipMemcpy(tmp, observations, (size_t)n * 4 * FRAME_PIX, hipMemcpyHostToDevice));
-  launch_obs_pack(c->stream, tmp, c->obs, n, train_map(c, 0)); // NOTE: overwrites rollout observation slots
-  net_forward(c, train_map(c, 0), n);
+  int rc = stage_observations(c, observations, n);
+  if (rc)
+    return rc;
+  // the packed stacks go to a staging area of their own: the rollout's observation slots are not touched
+  const size_t need = (size_t)n * FRAME_PIX * 4;
+  if (need > c->stage_obs_cap) {
+    if (c->stage_obs)
+      HIPCHK(c, hipFree(c->stage_obs));
+    c->stage_obs = nullptr;
+    c->stage_obs_cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->stage_obs), need));
+    c->stage_obs_cap = need;
+  }
+  const SampleMap map{1, (long)FRAME_PIX, 0, 0, 0}; // sample n at stage_obs + n * 7056
+  launch_obs_pack(c->stream, c->stage_u8, c->stage_obs, n, map);
+  net_forward(c, c->stage_obs, map, n);
   launch_heads_fwd(c->stream, c->h, Pf(c, P_WH), Pf(c, P_BH), c->logits_b, c->values_b, n, c->H, c->A);
   HIPCHK(c, hipMemcpyAsync(logits, c->logits_b, (size_t)n * c->A * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(values, c->values_b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  hipFree(tmp);
+  CHECK_ASYNC(c);
   return ALEPPO_OK;
 }
 
@@ -1140,7 +1225,13 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
   CHECK_CTX(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (option == ALEPPO_OPT_GENERIC_CONV)
-    set_patch_kernels(value == 0);
+    c->tune.patch_conv = value == 0;
+  else if (option == ALEPPO_OPT_FC_PIPE)
+    c->tune.fc_pipe = value != 0;
+  else if (option == ALEPPO_OPT_FC_PIPE_WGRAD)
+    c->tune.fc_pipe_wgrad = value != 0;
+  else if (option == ALEPPO_OPT_FUSED_ACT)
+    c->tune.fused_act = value != 0;
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
   else if (option == ALEPPO_OPT_SERIAL_UPDATE)
@@ -1206,6 +1297,9 @@ struct DevBuf {
       return set_err(nullptr, ALEPPO_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                         \
   } while (0)
 
+// ai::gae::gae through the production scan kernel: the host arrays are laid out as the rollout's time-major step
+// records + value plane (the layout aleppo_finish_rollout hands the kernel), gae_kernel runs with clamp = 0 (ai::gae::gae
+// does not clamp; Buffer::get does, buffer.cc:67) and the env-major advantage array comes back as is.
 extern "C" int aleppo_gae(int dev, float *advantages, const float *rewards, const float *values,
                           const float *next_values, const uint8_t *terminals, const uint8_t *truncations,
                           const uint8_t *episode_starts, int64_t E, int64_t T, float gamma, float lambda) {
@@ -1217,18 +1311,31 @@ extern "C" int aleppo_gae(int dev, float *advantages, const float *rewards, cons
   int rc = select_device(dev);
   if (rc)
     return rc;
-  const size_t n = (size_t)E * T;
-  DevBuf a, r, v, nv, te, tr, st, er;
+  set_tuning(nullptr);
+  const size_t n = (size_t)E * T, rb = ((size_t)7 * E + 15) / 16 * 16;
+  std::vector<uint8_t> rec(rb * T, 0);
+  std::vector<float> vtm((size_t)(T + 1) * E);
+  for (int64_t t = 0; t < T; ++t) {
+    uint8_t *r = rec.data() + (size_t)t * rb;
+    for (int64_t e = 0; e < E; ++e) {
+      reinterpret_cast<float *>(r)[e] = rewards[e * T + t];
+      r[4 * E + e] = terminals[e * T + t];
+      r[5 * E + e] = truncations[e * T + t];
+      r[6 * E + e] = episode_starts[e * T + t];
+      vtm[(size_t)t * E + e] = values[e * T + t];
+    }
+  }
+  for (int64_t e = 0; e < E; ++e)
+    vtm[(size_t)T * E + e] = next_values[e];
+  DevBuf drec, dv, a, r, m, er;
+  OPCHK(drec.up(rec.data(), rec.size()));
+  OPCHK(dv.up(vtm.data(), vtm.size() * 4));
   OPCHK(a.up(nullptr, n * 4));
-  OPCHK(r.up(rewards, n * 4));
-  OPCHK(v.up(values, n * 4));
-  OPCHK(nv.up(next_values, (size_t)E * 4));
-  OPCHK(te.up(terminals, n));
-  OPCHK(tr.up(truncations, n));
-  OPCHK(st.up(episode_starts, n));
+  OPCHK(r.up(nullptr, n * 4));
+  OPCHK(m.up(nullptr, n));
   OPCHK(er.up(nullptr, 16));
-  launch_gae_op(nullptr, a.as<float>(), r.as<float>(), v.as<float>(), nv.as<float>(), te.as<uint8_t>(),
-                tr.as<uint8_t>(), st.as<uint8_t>(), er.as<int>(), (int)E, (int)T, gamma, lambda);
+  launch_gae(nullptr, drec.as<uint8_t>(), rb, dv.as<float>(), nullptr, nullptr, a.as<float>(), r.as<float>(), nullptr,
+             nullptr, m.as<uint8_t>(), er.as<int>(), (int)E, (int)T, 0, gamma, lambda, /*clamp=*/false);
   int err = 0;
   OPCHK(hipMemcpy(&err, er.p, 4, hipMemcpyDeviceToHost));
   if (err)
@@ -1264,19 +1371,48 @@ extern "C" int aleppo_vision_rgb_to_gray(int dev, const float *images, float *ou
   OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX * 4, hipMemcpyDeviceToHost));
   return ALEPPO_OK;
 }
+
+// The two frame operators run the production ingest kernel on a scratch pair of observation slots
+// ([n][2 slots][7056] packed stacks, slot 0 = before, slot 1 = after) and convert at the boundary.
+static int ingest_op(bool raw, const uint8_t *frames, size_t frame_bytes, const uint8_t *lut256,
+                     const uint8_t *obs_nchw_in, const uint8_t *start, uint8_t *obs_nchw_out, int64_t n) {
+  if (n > MAX_ENVS_PER_RANK)
+    return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "at most 8192 environments per call");
+  DevBuf f, l, st, nchw, slots;
+  OPCHK(f.up(frames, frame_bytes));
+  uint8_t ident[256];
+  for (int i = 0; i < 256; ++i)
+    ident[i] = (uint8_t)i;
+  OPCHK(l.up(lut256 ? lut256 : ident, 256));
+  std::vector<uint8_t> ones;
+  if (!start) {
+    ones.assign((size_t)n, 1);
+    start = ones.data();
+  }
+  OPCHK(st.up(start, (size_t)n));
+  OPCHK(nchw.up(obs_nchw_in, (size_t)n * 4 * FRAME_PIX)); // (zeros when there is no previous stack)
+  OPCHK(slots.up(nullptr, (size_t)n * 2 * FRAME_PIX * 4));
+  launch_obs_pack(nullptr, nchw.as<uint8_t>(), slots.as<uint32_t>(), n, SampleMap{1, 2L * FRAME_PIX, 0, 0, 0});
+  launch_ingest(nullptr, raw, f.as<uint8_t>(), l.as<uint8_t>(), st.as<uint8_t>(), nullptr, slots.as<uint32_t>(), (int)n,
+                2, 0, 1);
+  launch_obs_unpack(nullptr, slots.as<uint32_t>(), nchw.as<uint8_t>(), n, SampleMap{1, 2L * FRAME_PIX, 0, FRAME_PIX, 0});
+  OPCHK(hipDeviceSynchronize());
+  OPCHK(hipMemcpy(obs_nchw_out, nchw.p, (size_t)n * 4 * FRAME_PIX, hipMemcpyDeviceToHost));
+  return ALEPPO_OK;
+}
 extern "C" int aleppo_preprocess(int dev, const uint8_t *raw_pairs, const uint8_t *lut256, uint8_t *out, int64_t n) {
   if (!raw_pairs || !out || n <= 0)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
   int rc = select_device(dev);
   if (rc)
     return rc;
-  DevBuf i, l, o;
-  OPCHK(i.up(raw_pairs, (size_t)n * 2 * RAW_H * RAW_W));
-  if (lut256)
-    OPCHK(l.up(lut256, 256));
-  OPCHK(o.up(nullptr, (size_t)n * FRAME_PIX));
-  launch_preprocess(nullptr, i.as<uint8_t>(), lut256 ? l.as<uint8_t>() : nullptr, o.as<uint8_t>(), n);
-  OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX, hipMemcpyDeviceToHost));
+  // every environment in an episode-start slot: the new frame is broadcast to all four stack planes; plane 0 is it
+  std::vector<uint8_t> stack((size_t)n * 4 * FRAME_PIX);
+  rc = ingest_op(true, raw_pairs, (size_t)n * 2 * RAW_H * RAW_W, lut256, nullptr, nullptr, stack.data(), n);
+  if (rc)
+    return rc;
+  for (int64_t e = 0; e < n; ++e)
+    std::memcpy(out + (size_t)e * FRAME_PIX, stack.data() + (size_t)e * 4 * FRAME_PIX, FRAME_PIX);
   return ALEPPO_OK;
 }
 extern "C" int aleppo_update_observations(int dev, uint8_t *observations, const uint8_t *frames,
@@ -1286,14 +1422,13 @@ extern "C" int aleppo_update_observations(int dev, uint8_t *observations, const 
   int rc = select_device(dev);
   if (rc)
     return rc;
-  DevBuf o, f, s;
-  OPCHK(o.up(observations, (size_t)E * 4 * FRAME_PIX));
-  OPCHK(f.up(frames, (size_t)E * FRAME_PIX));
-  OPCHK(s.up(episode_start, (size_t)E));
-  launch_update_obs_nchw(nullptr, o.as<uint8_t>(), f.as<uint8_t>(), s.as<uint8_t>(), E);
-  OPCHK(hipMemcpy(observations, o.p, (size_t)E * 4 * FRAME_PIX, hipMemcpyDeviceToHost));
-  return ALEPPO_OK;
+  return ingest_op(false, frames, (size_t)E * FRAME_PIX, nullptr, observations, episode_start, observations, E);
 }
+
+// ai::ppo::losses::compute through the production head kernel (head_train_kernel<float>): the caller's raw logits and
+// values become the first A + 1 components of a 32-wide hidden vector and the head weights an identity block, so the
+// kernel's "head linear layer" reproduces them exactly (x * 1 + 0 + ... is exact in fp32) and its dh output IS
+// (dlogits, dvalue).  The scalar loss is the masked mean the update reports (metrics_reduce_kernel, as aleppo_train).
 extern "C" int aleppo_ppo_loss(int dev, const float *logits, const float *old_lp, const int64_t *actions,
                                const float *advantages, const float *values, const float *returns,
                                const uint8_t *masks, int64_t B, int64_t A, float clip, float c_v, float c_e,
@@ -1302,36 +1437,73 @@ extern "C" int aleppo_ppo_loss(int dev, const float *logits, const float *old_lp
   if (!logits || !old_lp || !actions || !advantages || !values || !returns || !masks || B <= 0 || A <= 0 ||
       A > MAX_ACTIONS)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
-  for (int64_t i = 0; i < B; ++i)
+  std::vector<int> a32((size_t)B);
+  for (int64_t i = 0; i < B; ++i) {
     if (actions[i] < 0 || actions[i] >= A)
       return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "action index out of range");
+    a32[(size_t)i] = (int)actions[i];
+  }
   int rc = select_device(dev);
   if (rc)
     return rc;
-  DevBuf z, ol, ac, ad, va, re, ma, o[8];
-  OPCHK(z.up(logits, (size_t)B * A * 4));
+  constexpr int H = 32; // >= MAX_ACTIONS + 1
+  std::vector<float> h((size_t)B * H, 0.f), Wh((size_t)(A + 1) * H, 0.f), bh((size_t)A + 1, 0.f);
+  for (int64_t i = 0; i < B; ++i) {
+    for (int64_t k = 0; k < A; ++k)
+      h[(size_t)i * H + k] = logits[i * A + k];
+    h[(size_t)i * H + A] = values[i];
+  }
+  for (int64_t k = 0; k <= A; ++k)
+    Wh[(size_t)k * H + k] = 1.0f;
+  const int nblk = (int)std::min<int64_t>(MAXS_HEAD, (B + 15) / 16);
+  DevBuf dh_in, dW, db, ol, ac, ad, re, ma, cnt, dh_out, ps, sw, sb, red;
+  OPCHK(dh_in.up(h.data(), h.size() * 4));
+  OPCHK(dW.up(Wh.data(), Wh.size() * 4));
+  OPCHK(db.up(bh.data(), bh.size() * 4));
   OPCHK(ol.up(old_lp, (size_t)B * A * 4));
-  OPCHK(ac.up(actions, (size_t)B * 8));
+  OPCHK(ac.up(a32.data(), (size_t)B * 4));
   OPCHK(ad.up(advantages, (size_t)B * 4));
-  OPCHK(va.up(values, (size_t)B * 4));
   OPCHK(re.up(returns, (size_t)B * 4));
   OPCHK(ma.up(masks, (size_t)B));
-  const size_t osz[8] = {4, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4, (size_t)B * 4,
-                         (size_t)B * A * 4, (size_t)B * 4};
-  for (int k = 0; k < 8; ++k)
-    OPCHK(o[k].up(nullptr, osz[k]));
-  launch_ppo_loss_op(nullptr, z.as<float>(), ol.as<float>(), ac.as<int64_t>(), ad.as<float>(), va.as<float>(),
-                     re.as<float>(), ma.as<uint8_t>(), B, (int)A, Hyper{clip, c_v, c_e, 0.f}, o[0].as<float>(),
-                     o[1].as<float>(), o[2].as<float>(), o[3].as<float>(), o[4].as<float>(), o[5].as<float>(),
-                     o[6].as<float>(), o[7].as<float>());
-  float *hd[8] = {loss, clipped, value_losses, entropies, total_losses, ratio, dlogits, dvalues};
-  for (int k = 0; k < 8; ++k)
-    if (hd[k])
-      OPCHK(hipMemcpy(hd[k], o[k].p, osz[k], hipMemcpyDeviceToHost));
+  OPCHK(cnt.up(nullptr, 16));
+  OPCHK(dh_out.up(nullptr, (size_t)B * H * 4));
+  OPCHK(ps.up(nullptr, (size_t)5 * B * 4));
+  OPCHK(sw.up(nullptr, (size_t)nblk * (A + 1) * H * 4));
+  OPCHK(sb.up(nullptr, (size_t)nblk * (A + 1) * 4));
+  OPCHK(red.up(nullptr, 8 * 4));
+  launch_mask_count(nullptr, ma.as<uint8_t>(), cnt.as<float>(), B, 1); // losses.cc:19 masks.sum()
+  float *p = ps.as<float>();
+  launch_head_train(nullptr, dh_in.as<float>(), dW.as<float>(), db.as<float>(), ac.as<int>(), ol.as<float>(),
+                    ad.as<float>(), re.as<float>(), ma.as<uint8_t>(), cnt.as<float>(), Hyper{clip, c_v, c_e, 0.f},
+                    dh_out.p, ALEPPO_FP32, p, p + B, p + 2 * B, p + 3 * B, p + 4 * B, sw.as<float>(), sb.as<float>(),
+                    nblk, B, H, (int)A, nullptr, nullptr, 1, nullptr);
+  launch_metrics_reduce(nullptr, p, (size_t)B, ma.as<uint8_t>(), B, 1, 1, red.as<float>());
+  OPCHK(hipDeviceSynchronize());
+  float r8[8];
+  OPCHK(hipMemcpy(r8, red.p, sizeof(r8), hipMemcpyDeviceToHost));
+  if (loss)
+    *loss = r8[0] / r8[5];
+  float *per[5] = {total_losses, clipped, value_losses, entropies, ratio}; // order of the kernel's metric planes
+  for (int k = 0; k < 5; ++k)
+    if (per[k])
+      OPCHK(hipMemcpy(per[k], p + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToHost));
+  if (dlogits || dvalues) {
+    std::vector<float> d((size_t)B * H);
+    OPCHK(hipMemcpy(d.data(), dh_out.p, d.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < B; ++i) {
+      if (dlogits)
+        for (int64_t k = 0; k < A; ++k)
+          dlogits[i * A + k] = d[(size_t)i * H + k];
+      if (dvalues)
+        dvalues[i] = d[(size_t)i * H + A];
+    }
+  }
   return ALEPPO_OK;
 }
+// multinomial(probs, 1, true) given its noise through the production acting head (infer_head_kernel in its probs mode:
+// same division, same wave arg-max, same stores)
 extern "C" int aleppo_sample(int dev, const float *probs, const float *q, int64_t *actions, int64_t E, int64_t A) {
-  if (!probs || !q || !actions || E <= 0 || A <= 0)
+  if (!probs || !q || !actions || E <= 0 || A <= 0 || A > MAX_ACTIONS)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "bad argument");
   int rc = select_device(dev);
   if (rc)
@@ -1339,8 +1511,12 @@ extern "C" int aleppo_sample(int dev, const float *probs, const float *q, int64_
   DevBuf p, qq, a;
   OPCHK(p.up(probs, (size_t)E * A * 4));
   OPCHK(qq.up(q, (size_t)E * A * 4));
-  OPCHK(a.up(nullptr, (size_t)E * 8));
-  launch_sample_op(nullptr, p.as<float>(), qq.as<float>(), a.as<int64_t>(), E, (int)A);
-  OPCHK(hipMemcpy(actions, a.p, (size_t)E * 8, hipMemcpyDeviceToHost));
+  OPCHK(a.up(nullptr, (size_t)E * 4));
+  launch_infer_head(nullptr, nullptr, FC_SPLITS, nullptr, nullptr, nullptr, qq.as<float>(), 0, 0, nullptr, nullptr,
+                    a.as<int>(), nullptr, nullptr, 0, (int)E, 32, (int)A, p.as<float>());
+  std::vector<int> a32((size_t)E);
+  OPCHK(hipMemcpy(a32.data(), a.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+  for (int64_t e = 0; e < E; ++e)
+    actions[e] = a32[(size_t)e];
   return ALEPPO_OK;
 }

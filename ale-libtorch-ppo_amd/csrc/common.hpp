@@ -54,6 +54,19 @@ struct Hyper {
   float clip, c_v, c_e, max_norm;
 };
 
+// Kernel-selection switches of ONE context (aleppo_set_option; initial values from the environment, read once in
+// aleppo_create).  The launch helpers read them through tuning(): a thread-local pointer that every stateful entry
+// point aims at its context first - the switches are per context, not per process.
+struct Tuning {
+  bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
+  bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
+  bool fc_pipe_wgrad = false; // opt-in pipelined fc wgrad
+  bool fused_act = true;      // one persistent acting launch per slot (false: ingest / convs / fc / head launches)
+};
+const Tuning &tuning();
+void set_tuning(const Tuning *t); // nullptr -> process defaults
+Tuning tuning_from_env();
+
 struct Ctx {
   aleppo_config cfg{};
   int E = 0, T = 0, A = 0, H = 0, prec = 0, world = 1, rank = 0;
@@ -126,6 +139,13 @@ struct Ctx {
   int last_epochs = 0, last_M = 0;
   long last_B = 0;
   // ---- profiling ----
+  Tuning tune;
+  hipError_t async_err = hipSuccess; // first failure of a call whose status could not be returned on the spot
+  // ---- boundary staging (aleppo_set_batch / aleppo_forward): grown on demand, freed in aleppo_destroy
+  uint8_t *stage_u8 = nullptr;   // NCHW uint8 observations as uploaded
+  size_t stage_u8_cap = 0;
+  uint32_t *stage_obs = nullptr; // packed stacks of aleppo_forward's samples (never the rollout slots)
+  size_t stage_obs_cap = 0;
   bool prof_on = false;
   bool serial_update = false; // ALEPPO_OPT_SERIAL_UPDATE: every update kernel on the main stream
   bool dbg_no_publish = false;
@@ -152,10 +172,10 @@ void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, i
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
                        const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
                        float *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
-                       int H, int A);
+                       int H, int A, const float *probs_in = nullptr);
 void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
                 const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
-                int *err, int E, int T, int A, float gamma, float lambda);
+                int *err, int E, int T, int A, float gamma, float lambda, bool clamp = true);
 
 void launch_adv_norm(hipStream_t s, float *adv_n, const uint8_t *mask_n, float *stats, long n, int phase);
 void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long B, int M);
@@ -190,18 +210,9 @@ void launch_transpose_tm_pitched(hipStream_t s, const void *src_tm, size_t pitch
 void launch_heads_fwd(hipStream_t s, const float *h, const float *Wh, const float *bh, float *logits, float *values,
                       long n, int H, int A);
 void launch_logsoftmax_rows(hipStream_t s, const float *in, float *out, long rows, int A);
-// stateless operators
-void launch_gae_op(hipStream_t s, float *adv, const float *r, const float *v, const float *nv, const uint8_t *term,
-                   const uint8_t *trunc, const uint8_t *start, int *err, int E, int T, float gamma, float lambda);
+// float-in / float-out free functions of ai::vision (library-only in the reference, vision.cc:8-32,:71-84)
 void launch_area_resize(hipStream_t s, const float *in, float *out, long n);
 void launch_rgb_to_gray(hipStream_t s, const float *in, float *out, long n);
-void launch_preprocess(hipStream_t s, const uint8_t *raw, const uint8_t *lut, uint8_t *out, long n);
-void launch_update_obs_nchw(hipStream_t s, uint8_t *obs, const uint8_t *frames, const uint8_t *start, long E);
-void launch_ppo_loss_op(hipStream_t s, const float *logits, const float *oldlp, const int64_t *actions,
-                        const float *adv, const float *values, const float *ret, const uint8_t *mask, long B, int A,
-                        Hyper hp, float *loss, float *clipped, float *value_losses, float *entropies,
-                        float *total_losses, float *ratio, float *dlogits, float *dvalues);
-void launch_sample_op(hipStream_t s, const float *probs, const float *q, int64_t *actions, long E, int A);
 
 // ------------------------------------------------------------------ GEMM launchers (gemm_launch.hip)
 // prec selects T (ALEPPO_FP32 / ALEPPO_BF16); all pointers are device pointers of the matching type.
@@ -228,8 +239,7 @@ int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, S
                 float *slab_b, long ns);
 
 // ------------------------------------------------------------------ sample-stationary bf16 conv kernels (conv_patch_launch.hip)
-bool use_patch_kernels(); // false when ALEPPO_GENERIC_CONV=1
-void set_patch_kernels(bool on);
+inline bool use_patch_kernels() { return tuning().patch_conv; } // false: ALEPPO_OPT_GENERIC_CONV / ALEPPO_GENERIC_CONV=1
 void patch_conv1_fwd(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, void *a1,
                      long ns);
 void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float *b2, void *a2, long ns);

@@ -20,16 +20,6 @@ static int num_cus() {
   return n;
 }
 
-static int g_patch = -1;
-bool use_patch_kernels() {
-  if (g_patch < 0) {
-    const char *e = std::getenv("ALEPPO_GENERIC_CONV"); // =1 forces the generic gather-GEMMs (A/B testing)
-    g_patch = (e && e[0] == '1') ? 0 : 1;
-  }
-  return g_patch == 1;
-}
-void set_patch_kernels(bool on) { g_patch = on ? 1 : 0; }
-
 template <class K> static void allow_smem(K kernel, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes);

@@ -9,7 +9,9 @@
 
 namespace aleppo {
 
-static int tune(const char *name, int dflt) { // tile-shape A/B switches (read once)
+// tile-shape A/B switches: every call site keeps its value in a function-local static (read once per process); the
+// switches the tests flip at run time (fc_pipe, fc_pipe_wgrad, patch_conv) are per-context options (tuning())
+static int tune(const char *name, int dflt) {
   const char *e = std::getenv(name);
   return e ? std::atoi(e) : dflt;
 }
@@ -87,7 +89,15 @@ template <int MODE, int NST> static void launch_pipe(hipStream_t s, const PipePa
   const int grid = P.njobs >= cus / 4 ? std::min(cus, ((P.njobs + rounds - 1) / rounds + 7) / 8 * 8) : std::min(P.njobs, cus);
   hipLaunchKernelGGL((gemm_pipe_kernel<MODE, NST>), dim3(grid), dim3(512), sm, s, P);
 }
-static bool use_pipe() { return tune("ALEPPO_FC_PIPE", 1) != 0; }
+static bool fc_dma() {
+  static const bool v = tune("ALEPPO_FC_DMA", 1) != 0;
+  return v;
+}
+static bool tn_xcd() {
+  static const bool v = tune("ALEPPO_TN_XCD", 1) != 0;
+  return v;
+}
+static bool use_pipe() { return tuning().fc_pipe; }
 // forward: h partial slabs [parts][ns][H]; parts chosen so that the jobs fill the CUs with the fewest rounds
 static int fc_fwd_pipe(hipStream_t s, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H,
                        int max_parts) {
@@ -156,7 +166,7 @@ static int fc_wgrad_pipe_slices(long ns, int H) {
 // rate (not LDS conflicts, not the dh row pitch, not XCD placement: all measured).  Kept as an opt-in
 // (ALEPPO_FC_PIPE_WGRAD=1) that the parity tests cover; the default is the gemm_tn kernel.
 bool fc_wgrad_pipelined(int prec, long ns, int H) {
-  return prec == ALEPPO_BF16 && use_pipe() && tune("ALEPPO_FC_PIPE_WGRAD", 0) && ns > 256 && ns % 64 == 0 && H % 8 == 0 &&
+  return prec == ALEPPO_BF16 && use_pipe() && tuning().fc_pipe_wgrad && ns > 256 && ns % 64 == 0 && H % 8 == 0 &&
          H >= 8 && fc_wgrad_pipe_slices(ns, H) >= 2;
 }
 static int fc_wgrad_pipe(hipStream_t s, const void *dh, const void *a3, float *sw, long ns, int H) {
@@ -187,7 +197,7 @@ static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float
   if (ns <= 256) // acting batch: smaller M tile so more workgroups share the 3136-deep reduction
     hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 32, 32, 2, 2>), grid2(ns, 32, H, 32), dim3(256), 0, s, ap, bp,
                        ep, (int)ns, H, FC_IN);
-  else if (tune("ALEPPO_FC_DMA", 1) && FC_IN % Atom<T>::KT == 0) {
+  else if (fc_dma() && FC_IN % Atom<T>::KT == 0) {
     static const int v = tune("ALEPPO_FC_FWD_TILE", 1);
     const T *a = static_cast<const T *>(a3), *b = static_cast<const T *>(Wfc);
     if (v == 3 && FC_IN % (2 * Atom<T>::KT) == 0)
@@ -252,7 +262,7 @@ static void fc_dgrad_t(hipStream_t s, const void *dh, const void *WfcT, const vo
   typename BL::P bp{static_cast<const T *>(WfcT), H, 0};
   typename EP::P ep{static_cast<T *>(dz3), static_cast<const T *>(a3), FC_IN, 0};
   static const int v = tune("ALEPPO_FC_DGRAD_TILE", 1);
-  if (tune("ALEPPO_FC_DMA", 1) && H % Atom<T>::KT == 0) {
+  if (fc_dma() && H % Atom<T>::KT == 0) {
     const T *a = static_cast<const T *>(dh), *b = static_cast<const T *>(WfcT);
     if (v == 3)
       hipLaunchKernelGGL((gemm_nt_dma_kernel<T, EP, 64, 64, 2, 2, 16>), grid2(ns, 64, FC_IN, 64), dim3(256), 0, s, a, H,
@@ -337,7 +347,7 @@ template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const vo
   typename AL::P ap{static_cast<const T *>(dh), H, 0};
   typename BL::P bp{static_cast<const T *>(a3), FC_IN, 0};
   // contiguous per-XCD work chunks (the m-tiles sharing an a3 stream on one L2) when the block count allows
-  auto swz = [&](const dim3 &g) { return ((g.x * g.y * S) % 8 == 0 && tune("ALEPPO_TN_XCD", 1)) ? (int)(g.x | (g.y << 12)) : 0; };
+  auto swz = [&](const dim3 &g) { return ((g.x * g.y * S) % 8 == 0 && tn_xcd()) ? (int)(g.x | (g.y << 12)) : 0; };
   auto grid = [&](const dim3 &g, int xsw) { return xsw ? dim3(g.x * g.y * S) : dim3(g.x, g.y, S); };
   if (v == 1) {
     const dim3 g = grid2(H, 64, FC_IN, 64);

@@ -142,50 +142,56 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 // Hand-off to the host: actions go to pinned memory, then ONE ticket word is published after every wave's
 // stores are system-visible (fence + device counter, last wave publishes) - the host polls the ticket instead
 // of synchronising the stream, so PCIe write latency overlaps the host's next enqueue.
+// probs_in != nullptr (the stateless aleppo_sample operator, train.cc:374-375 alone): the head is skipped and lane k
+// takes p_k from probs_in[e][k]; the division, the arg-max and the stores are the very same instructions.
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ hpart, const float *__restrict__ bfc,
                                                           const float *__restrict__ Wh, const float *__restrict__ bh,
                                                           const float *__restrict__ noise, uint64_t seed,
                                                           uint64_t counter, float *logits_t, float *values_t,
                                                           int *actions_t, int64_t *pinned, unsigned int *done_ctr,
-                                                          long long ticket, int E, int H, int A) {
+                                                          long long ticket, int E, int H, int A,
+                                                          const float *__restrict__ probs_in) {
   extern __shared__ float sWh[]; // [(A+1)][H] head weights: ONE parallel round trip for the whole workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 4 + wave;
   // Lane l owns hidden units 4l .. 4l+3 and H/2 + 4l .. (H <= 512, H % 8 == 0): two 16-byte loads per split-K slice
   // instead of eight scalar ones (the kernel is latency-bound on ~70 vector-memory instructions per wave; now 18),
   // consecutive lanes on consecutive 16-byte pieces (coalesced, conflict-free LDS reads of the head weights).
-  float hv[8];
-  f32x4 part[NSPLIT][2];
-  const bool own = e < E && lane * 8 < H;
+  float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool heads = probs_in == nullptr; // workgroup-uniform
+  if (heads) {
+    f32x4 part[NSPLIT][2];
+    const bool own = e < E && lane * 8 < H;
 #pragma unroll
-  for (int z = 0; z < NSPLIT; ++z) { // issue every split-K partial load first (independent)
-    const float *src = hpart + ((size_t)z * E + (own ? e : 0)) * H + (own ? lane * 4 : 0);
-    part[z][0] = *reinterpret_cast<const f32x4 *>(src);
-    part[z][1] = *reinterpret_cast<const f32x4 *>(src + H / 2);
-  }
-  {
-    const float *b = bfc + (own ? lane * 4 : 0);
-    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b), b1 = *reinterpret_cast<const f32x4 *>(b + H / 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      hv[i] = b0[i];
-      hv[4 + i] = b1[i];
+    for (int z = 0; z < NSPLIT; ++z) { // issue every split-K partial load first (independent)
+      const float *src = hpart + ((size_t)z * E + (own ? e : 0)) * H + (own ? lane * 4 : 0);
+      part[z][0] = *reinterpret_cast<const f32x4 *>(src);
+      part[z][1] = *reinterpret_cast<const f32x4 *>(src + H / 2);
     }
-  }
-  for (int k = threadIdx.x; k < (A + 1) * H / 4; k += 256)
-    reinterpret_cast<f32x4 *>(sWh)[k] = reinterpret_cast<const f32x4 *>(Wh)[k];
+    {
+      const float *b = bfc + (own ? lane * 4 : 0);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b), b1 = *reinterpret_cast<const f32x4 *>(b + H / 2);
 #pragma unroll
-  for (int z = 0; z < NSPLIT; ++z)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      hv[i] += part[z][0][i];
-      hv[4 + i] += part[z][1][i];
+      for (int i = 0; i < 4; ++i) {
+        hv[i] = b0[i];
+        hv[4 + i] = b1[i];
+      }
     }
+    for (int k = threadIdx.x; k < (A + 1) * H / 4; k += 256)
+      reinterpret_cast<f32x4 *>(sWh)[k] = reinterpret_cast<const f32x4 *>(Wh)[k];
+#pragma unroll
+    for (int z = 0; z < NSPLIT; ++z)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hv[i] += part[z][0][i];
+        hv[4 + i] += part[z][1][i];
+      }
+  }
   __syncthreads();
   if (e < E) {
     float zmine = 0.f; // lane a keeps logit a (a < A) / the value (a == A)
-    for (int a = 0; a <= A; ++a) {
+    for (int a = 0; heads && a <= A; ++a) {
       float s = 0.f;
       if (lane * 8 < H) {
         const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sWh + a * H + lane * 4);
@@ -222,7 +228,10 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
         q = -logf(((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f)); // u in (0,1)
       }
     }
-    float r = isact ? (ex / sum) / q : -1.f; // p_k / q_k (train.cc:374-375)
+    float pk = ex / sum; // softmax (train.cc:374)
+    if (!heads)
+      pk = isact ? probs_in[(size_t)e * A + lane] : 0.f;
+    float r = isact ? pk / q : -1.f; // p_k / q_k (train.cc:374-375)
     int best = lane;
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) { // arg-max, ties -> lowest index (first maximum wins)
@@ -233,9 +242,9 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
         best = bo;
       }
     }
-    if (isact)
+    if (heads && isact)
       logits_t[(size_t)e * A + lane] = zmine;
-    if (lane == A)
+    if (heads && lane == A)
       values_t[e] = zmine;
     if (lane == 0) {
       actions_t[e] = best;
@@ -265,11 +274,11 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
                        const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
                        float *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
-                       int H, int A) {
+                       int H, int A, const float *probs_in) {
   (void)nsplit; // always FC_SPLITS on the acting path
   hipLaunchKernelGGL(infer_head_kernel<FC_SPLITS>, dim3((E + 3) / 4), dim3(256), (size_t)(A + 1) * H * sizeof(float), s,
                      hpart, bfc, Wh, bh, noise, seed, counter, logits_t, values_t, actions_t, pinned, done_ctr, ticket, E,
-                     H, A);
+                     H, A, probs_in);
 }
 
 // ================================================================================================
@@ -310,7 +319,7 @@ struct GaeChunk {
 __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const float *__restrict__ values_tm,
                                                   const float *__restrict__ logits_tm, const int *__restrict__ actions_tm,
                                                   float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
-                                                  int *err, int E, int T, int A, float gamma, float lambda) {
+                                                  int *err, int E, int T, int A, float gamma, float lambda, int clamp) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E)
     return;
@@ -324,8 +333,11 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
   float last = 0.f, nv = values_tm[(size_t)T * E + e];
   int bad = 0;
   auto step = [&](int t, float r, float v, bool bte, bool btr, bool bst) {
-    const float rc = fminf(fmaxf(r, -1.0f), 1.0f); // buffer.cc:67 clamp_, in place
-    reinterpret_cast<float *>(rec + (size_t)t * rb)[e] = rc;
+    // buffer.cc:67 clamp_, in place (Buffer::get).  clamp == 0: ai::gae::gae alone (the stateless aleppo_gae
+    // operator) - rewards are used as given and left untouched.
+    const float rc = clamp ? fminf(fmaxf(r, -1.0f), 1.0f) : r;
+    if (clamp)
+      reinterpret_cast<float *>(rec + (size_t)t * rb)[e] = rc;
     bad |= ((int)bte + (int)btr + (int)bst > 1) ? 1 : 0; // gae.cc:49-53
     const float a = gae_step(rc, v, nv, last, gamma, gl, bst, bte, btr);
     const size_t n = (size_t)e * T + t;
@@ -404,37 +416,12 @@ __global__ void oldlp_kernel(const float *__restrict__ logits_tm, const int *__r
 }
 void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
                 const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
-                int *err, int E, int T, int A, float gamma, float lambda) {
-  hipLaunchKernelGGL(oldlp_kernel, dim3((unsigned)(((long)E * T + 255) / 256)), dim3(256), 0, s, logits_tm, actions_tm,
-                     oldlp_n, act_n, E, T, A);
+                int *err, int E, int T, int A, float gamma, float lambda, bool clamp) {
+  if (logits_tm) // (the stateless aleppo_gae operator has no logits / actions)
+    hipLaunchKernelGGL(oldlp_kernel, dim3((unsigned)(((long)E * T + 255) / 256)), dim3(256), 0, s, logits_tm, actions_tm,
+                       oldlp_n, act_n, E, T, A);
   hipLaunchKernelGGL(gae_kernel, dim3((E + 63) / 64), dim3(64), 0, s, step_rec, rec_bytes, values_tm, logits_tm,
-                     actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n, err, E, T, A, gamma, lambda);
-}
-
-// stateless ai::gae::gae on env-major host-layout arrays (parity tests)
-__global__ void gae_op_kernel(float *adv, const float *r, const float *v, const float *nv0, const uint8_t *term,
-                              const uint8_t *trunc, const uint8_t *start, int *err, int E, int T, float gamma,
-                              float lambda) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E)
-    return;
-  const float gl = gamma * lambda;
-  float last = 0.f, nv = nv0[e];
-  for (int t = T - 1; t >= 0; --t) {
-    const size_t k = (size_t)e * T + t;
-    const bool te = term[k] != 0, tr = trunc[k] != 0, st = start[k] != 0;
-    if ((int)te + (int)tr + (int)st > 1)
-      *err = 1;
-    const float a = gae_step(r[k], v[k], nv, last, gamma, gl, st, te, tr);
-    adv[k] = a;
-    last = a;
-    nv = v[k];
-  }
-}
-void launch_gae_op(hipStream_t s, float *adv, const float *r, const float *v, const float *nv, const uint8_t *term,
-                   const uint8_t *trunc, const uint8_t *start, int *err, int E, int T, float gamma, float lambda) {
-  hipLaunchKernelGGL(gae_op_kernel, dim3((E + 63) / 64), dim3(64), 0, s, adv, r, v, nv, term, trunc, start, err, E, T,
-                     gamma, lambda);
+                     actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n, err, E, T, A, gamma, lambda, clamp ? 1 : 0);
 }
 
 // optional advantage normalisation over unmasked samples (NOT in the reference, Q2; off by default).
@@ -458,7 +445,10 @@ __global__ __launch_bounds__(256) void adv_norm_kernel(float *adv, const uint8_t
       stats[2] = c;
     }
   } else {
-    const float c = stats[2], mean = stats[0] / c;
+    const float c = stats[2];
+    if (!(c > 0.f)) // every sample masked: nothing to normalise (and nothing enters the loss)
+      return;
+    const float mean = stats[0] / c;
     const float var = fmaxf((stats[1] - c * mean * mean) / fmaxf(c - 1.f, 1.f), 0.f);
     const float inv = 1.0f / (sqrtf(var) + 1e-8f);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
@@ -1213,143 +1203,4 @@ __global__ void rgb_to_gray_kernel(const float *in, float *out) {
 void launch_rgb_to_gray(hipStream_t s, const float *in, float *out, long n) {
   hipLaunchKernelGGL(rgb_to_gray_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)n), dim3(256), 0, s, in, out);
 }
-// fused device preprocessing alone: [n][2][210][160] u8 -> [n][84][84] u8 (same arithmetic as ingest_kernel<true>)
-__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ lut,
-                                                          uint8_t *out) {
-  const int e = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
-  __shared__ __attribute__((aligned(16))) uint8_t sraw[2 * 30 * RAW_W];
-  __shared__ uint8_t slut[256];
-  for (int v = tid; v < 600; v += 256) {
-    const int f = v / 300, r = v - f * 300;
-    const u32x4 *src =
-        reinterpret_cast<const u32x4 *>(raw + ((size_t)e * 2 + f) * (RAW_H * RAW_W) + (size_t)band * 30 * RAW_W);
-    reinterpret_cast<u32x4 *>(sraw)[v] = src[r];
-  }
-  slut[tid] = lut ? lut[tid] : (uint8_t)tid;
-  __syncthreads();
-  for (int pix = tid; pix < 12 * 84; pix += 256) {
-    const int il = pix / 84, j = pix - il * 84, i = band * 12 + il;
-    const int y0 = (i * RAW_H) / 84 - band * 30, y1 = ((i + 1) * RAW_H + 83) / 84 - band * 30;
-    const int x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84;
-    int best = 0;
-    for (int f = 0; f < 2; ++f) {
-      int s = 0;
-      for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x)
-          s += slut[sraw[(f * 30 + y) * RAW_W + x]];
-      best = max(best, (int)rintf((float)s / (float)((y1 - y0) * (x1 - x0))));
-    }
-    out[(size_t)e * FRAME_PIX + i * 84 + j] = (uint8_t)min(best, 255);
-  }
-}
-void launch_preprocess(hipStream_t s, const uint8_t *raw, const uint8_t *lut, uint8_t *out, long n) {
-  hipLaunchKernelGGL(preprocess_kernel, dim3(7, (unsigned)n), dim3(256), 0, s, raw, lut, out);
-}
-// rollout.cc:184-196 on reference-layout NCHW u8 [E][4][84][84]
-__global__ void update_obs_nchw_kernel(uint8_t *obs, const uint8_t *frames, const uint8_t *start) {
-  const long e = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= FRAME_PIX)
-    return;
-  uint8_t *o = obs + (size_t)e * 4 * FRAME_PIX + i;
-  const uint8_t f = frames[(size_t)e * FRAME_PIX + i];
-  if (start[e]) {
-    o[0] = o[FRAME_PIX] = o[2 * FRAME_PIX] = o[3 * FRAME_PIX] = f;
-  } else {
-    o[3 * FRAME_PIX] = o[2 * FRAME_PIX];
-    o[2 * FRAME_PIX] = o[FRAME_PIX];
-    o[FRAME_PIX] = o[0];
-    o[0] = f;
-  }
-}
-void launch_update_obs_nchw(hipStream_t s, uint8_t *obs, const uint8_t *frames, const uint8_t *start, long E) {
-  hipLaunchKernelGGL(update_obs_nchw_kernel, dim3((FRAME_PIX + 255) / 256, (unsigned)E), dim3(256), 0, s, obs, frames,
-                     start);
-}
-
-// losses.cc:4-47 forward + closed-form backward on raw logits, one thread per sample; block 0 reduces the loss
-__global__ __launch_bounds__(256) void ppo_loss_op_kernel(const float *logits, const float *oldlp, const int64_t *actions,
-                                                           const float *adv, const float *values, const float *ret,
-                                                           const uint8_t *mask, long B, int A, Hyper hp, float *loss,
-                                                           float *clipped, float *value_losses, float *entropies,
-                                                           float *total_losses, float *ratio, float *dlogits,
-                                                           float *dvalues) {
-  __shared__ float s4[4];
-  float cnt = 0.f;
-  for (long i = threadIdx.x; i < B; i += 256)
-    cnt += mask[i] ? 1.f : 0.f;
-  cnt = block_sum_256(cnt, s4);
-  float lsum = 0.f;
-  for (long i = threadIdx.x; i < B; i += 256) {
-    const float *z = logits + i * A;
-    float mx = z[0];
-    for (int k = 1; k < A; ++k)
-      mx = fmaxf(mx, z[k]);
-    float se = 0.f;
-    for (int k = 0; k < A; ++k)
-      se += expf(z[k] - mx);
-    const float lse = mx + logf(se);
-    const int ai = (int)actions[i];
-    float ent = 0.f;
-    for (int k = 0; k < A; ++k) {
-      const float lp = z[k] - lse;
-      ent += expf(lp) * lp;
-    }
-    ent = -ent;
-    const float lpa = z[ai] - lse;
-    const float rho = expf(lpa - oldlp[i * A + ai]);
-    const float crho = fminf(fmaxf(rho, 1.0f - hp.clip), 1.0f + hp.clip);
-    const float obj = fminf(rho * adv[i], crho * adv[i]);
-    const float dv = values[i] - ret[i];
-    const float lv = 0.5f * (dv * dv);
-    const float L = -obj + hp.c_v * lv - hp.c_e * ent;
-    if (mask[i])
-      lsum += L;
-    if (clipped) clipped[i] = obj;
-    if (value_losses) value_losses[i] = lv;
-    if (entropies) entropies[i] = ent;
-    if (total_losses) total_losses[i] = L;
-    if (ratio) ratio[i] = rho;
-    if (dlogits) {
-      const float m = mask[i] ? 1.0f / cnt : 0.f;
-      const bool active = adv[i] >= 0.f ? (rho <= 1.0f + hp.clip) : (rho >= 1.0f - hp.clip);
-      const float gs = active ? -rho * adv[i] : 0.f;
-      for (int k = 0; k < A; ++k) {
-        const float lp = z[k] - lse, p = expf(lp);
-        dlogits[i * A + k] = m * (gs * ((k == ai ? 1.f : 0.f) - p) + hp.c_e * p * (lp + ent));
-      }
-      dvalues[i] = m * hp.c_v * dv;
-    }
-  }
-  lsum = block_sum_256(lsum, s4);
-  if (threadIdx.x == 0 && loss)
-    *loss = lsum / cnt;
-}
-void launch_ppo_loss_op(hipStream_t s, const float *logits, const float *oldlp, const int64_t *actions,
-                        const float *adv, const float *values, const float *ret, const uint8_t *mask, long B, int A,
-                        Hyper hp, float *loss, float *clipped, float *value_losses, float *entropies,
-                        float *total_losses, float *ratio, float *dlogits, float *dvalues) {
-  hipLaunchKernelGGL(ppo_loss_op_kernel, dim3(1), dim3(256), 0, s, logits, oldlp, actions, adv, values, ret, mask, B,
-                     A, hp, loss, clipped, value_losses, entropies, total_losses, ratio, dlogits, dvalues);
-}
-// train.cc:374-375 given the exponential noise: argmax(p/q), first max wins; IEEE division -> bit-exact
-__global__ void sample_op_kernel(const float *probs, const float *q, int64_t *actions, long E, int A) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= E)
-    return;
-  int best = 0;
-  float bv = __fdiv_rn(probs[e * A], q[e * A]);
-  for (int k = 1; k < A; ++k) {
-    const float v = __fdiv_rn(probs[e * A + k], q[e * A + k]);
-    if (v > bv) {
-      bv = v;
-      best = k;
-    }
-  }
-  actions[e] = best;
-}
-void launch_sample_op(hipStream_t s, const float *probs, const float *q, int64_t *actions, long E, int A) {
-  hipLaunchKernelGGL(sample_op_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, probs, q, actions, E, A);
-}
-
 } // namespace aleppo

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ALEPPO_ABI_VERSION 1
+#define ALEPPO_ABI_VERSION 2
 
 typedef enum {
   ALEPPO_OK = 0,
@@ -34,7 +34,16 @@ typedef enum {
 } aleppo_status;
 
 typedef enum { ALEPPO_FP32 = 0, ALEPPO_BF16 = 1 } aleppo_precision;
-typedef enum { ALEPPO_HOST = 0, ALEPPO_DEVICE = 1 } aleppo_location;
+/* Storage type of the rollout buffer's float planes (values, logits, advantages, returns, old log-probs:
+ * Buffer's f32 tensors, src/ai/buffer.cc:12-38).  FP16 = BASELINE configs[4] "fp16 rollout buffer": the planes are
+ * rounded to IEEE half when stored; reward clamp / GAE / returns / log-softmax arithmetic stays fp32 on the rounded
+ * inputs; aleppo_read_batch still returns float.  The reference has only FP32. */
+typedef enum { ALEPPO_ROLLOUT_FP32 = 0, ALEPPO_ROLLOUT_FP16 = 1 } aleppo_rollout_precision;
+/* ALEPPO_HOST: ordinary or page-locked host memory, staged and copied by the call.  ALEPPO_DEVICE: device memory.
+ * ALEPPO_HOST_MAPPED: page-locked host memory the GPU can address (hipHostMalloc / hipHostRegister'ed, e.g. the ring
+ * the emulator threads write their frames into, src/ai/rollout.cc:325-326): the ingest kernel reads it in place over
+ * the bus - no staging copy, no separate copy command on the slot's critical path. */
+typedef enum { ALEPPO_HOST = 0, ALEPPO_DEVICE = 1, ALEPPO_HOST_MAPPED = 2 } aleppo_location;
 
 /* What aleppo_push_frames receives per environment step. */
 typedef enum {
@@ -63,6 +72,7 @@ typedef struct {
   int32_t precision;      /* aleppo_precision of the conv/linear stack */
   int32_t advantage_norm; /* 0 = none (the reference has none); 1 = normalise over masked samples */
   int32_t max_minibatch;  /* largest minibatch (samples per rank) aleppo_train will be asked for; 0 = E*T */
+  int32_t rollout_precision; /* aleppo_rollout_precision; 0 = float planes like the reference */
   float gamma, lambda;    /* gae_discount, gae_lambda */
   float clip_param, value_loss_coef, entropy_coef, max_gradient_norm;
   float adam_beta1, adam_beta2, adam_eps; /* 0 -> 0.9 / 0.999 / 1e-5 (train.cc:360-362) */
@@ -162,12 +172,15 @@ int aleppo_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int loca
 /* Rollout::rollout()'s slot loop (rollout.cc:198-278) over a PRE-RECORDED environment trace: for t in [0, T):
  * aleppo_act (built-in RNG) then aleppo_step with slot t of the trace.  frames: DEVICE memory, slot t at
  * frames + t * slot_stride_bytes (16-byte aligned); rewards [T][E] f32 and terminated / truncated / episode_start
- * [T][E] u8 are HOST arrays.  The sampled actions do not influence a recorded trace, so this entry point only
- * serves replay / throughput measurement with the whole host loop native (like the reference's C++ loop); a live
- * emulator calls aleppo_act / aleppo_step itself.  Leaves the context ready for aleppo_finish_rollout. */
-int aleppo_replay_rollout(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, size_t slot_stride_bytes,
-                          const float *rewards, const uint8_t *terminated, const uint8_t *truncated,
-                          const uint8_t *episode_start);
+ * [T][E] u8 are HOST arrays.  frame_location: ALEPPO_DEVICE or ALEPPO_HOST_MAPPED (the whole trace in mapped
+ * page-locked host memory: what a ring filled by emulator threads looks like to the device).  noise: float
+ * [T][E][A] Exp(1) draws (host) for a reproducible action stream, or NULL for the built-in generator.  The sampled
+ * actions do not influence a recorded trace, so this entry point only serves replay / throughput measurement with
+ * the whole host loop native (like the reference's C++ loop); a live emulator calls aleppo_act / aleppo_step itself.
+ * Leaves the context ready for aleppo_finish_rollout. */
+int aleppo_replay_rollout(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int frame_location,
+                          size_t slot_stride_bytes, const float *rewards, const uint8_t *terminated,
+                          const uint8_t *truncated, const uint8_t *episode_start, const float *noise);
 
 /* Tail of Rollout::rollout (rollout.cc:268-270) + Buffer::get (buffer.cc:58-77) + prepare_batch
  * (train.cc:272-283): bootstrap forward (draws and discards one sample like the reference), reward
@@ -205,7 +218,9 @@ int aleppo_comm_unique_id(uint8_t id[ALEPPO_UNIQUE_ID_BYTES]);
 int aleppo_comm_init(aleppo_ctx *ctx, const uint8_t id[ALEPPO_UNIQUE_ID_BYTES]);
 
 /* ------------------------------------------------------------------ stateless operators (host in / host out)
- * The reference's free functions, for parity tests that read like the reference's own tests. */
+ * The reference's free functions, for parity tests that read like the reference's own tests.  Each one converts
+ * its host tensors to the hot path's device layout and launches the SAME kernel the rollout / update launches
+ * (gae_kernel, ingest_kernel, head_train_kernel, infer_head_kernel): there is no second implementation. */
 /* ai::gae::gae (src/ai/gae.h:4-7): env-major [E,T]; same validation errors (gae.cc:8-53). */
 int aleppo_gae(int device_ordinal, float *advantages, const float *rewards, const float *values,
                const float *next_values, const uint8_t *terminals, const uint8_t *truncations,
@@ -256,14 +271,20 @@ typedef enum {
 int aleppo_profile_enable(aleppo_ctx *ctx, int on);
 int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);
 int aleppo_profile_reset(aleppo_ctx *ctx);
-/* Process-wide tuning / A-B switches.  ALEPPO_OPT_GENERIC_CONV = 1: run the bf16 convolutions on the generic
+/* Per-context tuning / A-B switches.  ALEPPO_OPT_GENERIC_CONV = 1: run the bf16 convolutions on the generic
  * gather-GEMM kernels instead of the sample-stationary ones (same math, used by the parity tests). */
 typedef enum {
   ALEPPO_OPT_GENERIC_CONV = 0,
   ALEPPO_OPT_DEBUG_NO_PUBLISH = 1, /* diagnosis only: the head kernel skips the pinned-memory hand-off */
   ALEPPO_OPT_FORCE_COMM = 2,       /* tests: run the RCCL all-reduce path even with a 1-rank communicator */
-  ALEPPO_OPT_SERIAL_UPDATE = 3     /* measurement: run the weight-gradient kernels on the main stream too (isolated
+  ALEPPO_OPT_SERIAL_UPDATE = 3,    /* measurement: run the weight-gradient kernels on the main stream too (isolated
                                       per-kernel timings; default 0 = co-scheduled on a second stream) */
+  ALEPPO_OPT_FC_PIPE = 4,          /* 0: small-tile fc GEMMs instead of the pipelined LDS-DMA ones (A/B, parity tests) */
+  ALEPPO_OPT_FC_PIPE_WGRAD = 5,    /* 1: pipelined fc weight gradient (opt-in, measured slower) */
+  ALEPPO_OPT_FUSED_ACT = 6,        /* 0: acting as separate ingest / conv / fc / head launches (A/B, parity tests) */
+  ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
+                                      (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
+                                      corrections are device scalars, so a replay follows the annealed rate */
 } aleppo_option;
 int aleppo_set_option(aleppo_ctx *ctx, int option, int value);
 /* Block until everything enqueued on ctx's streams has finished. */

@@ -545,3 +545,31 @@ int oracle_train(float *params, float *adam_m, float *adam_v, int64_t *adam_step
   free(grads);
   return 0;
 }
+
+/* ------------------------------------------------------------------ advantage normalisation
+ * NOT in the reference (grep over src/ finds no advantage normalisation) - BASELINE.json's north_star
+ * lists it, the library offers it as an off-by-default extension.  PARITY UNPINNED: no reference function, test or
+ * fixture covers it; this is the textbook definition the extension follows: over the unmasked samples
+ * (masks = !episode_starts, src/ai/buffer.cc:74) adv <- (adv - mean) / (std + 1e-8) with the unbiased standard
+ * deviation (torch.Tensor.std default); masked samples are transformed too (they never enter the loss).
+ * Accumulates in double: it is the checker.  returns the unmasked count. */
+long oracle_adv_norm(float *adv, const uint8_t *masks, long n) {
+  double s = 0.0, q = 0.0;
+  long c = 0;
+  for (long i = 0; i < n; ++i)
+    if (masks[i]) {
+      s += adv[i];
+      q += (double)adv[i] * adv[i];
+      ++c;
+    }
+  if (c == 0)
+    return 0;
+  const double mean = s / (double)c;
+  double var = (q - (double)c * mean * mean) / (double)(c > 1 ? c - 1 : 1);
+  if (var < 0.0)
+    var = 0.0;
+  const double inv = 1.0 / (sqrt(var) + 1e-8);
+  for (long i = 0; i < n; ++i)
+    adv[i] = (float)(((double)adv[i] - mean) * inv);
+  return c;
+}

@@ -79,6 +79,9 @@ int oracle_train(float *params, float *adam_m, float *adam_v, int64_t *adam_step
                  const uint8_t *masks, int N, int epochs, int M, double lr, float clip, float c_v, float c_e,
                  float max_norm, float *loss, float *grad_norm, float *total_losses, float *ratio, float *entropies,
                  float *value_losses, float *clipped, float *last_grads);
+/* advantage normalisation over unmasked samples - an extension with NO reference counterpart:
+ * PARITY UNPINNED, see oracle.c.  returns the unmasked count. */
+long oracle_adv_norm(float *adv, const uint8_t *masks, long n);
 int oracle_num_threads(void);
 #ifdef __cplusplus
 }

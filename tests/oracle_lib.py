@@ -169,6 +169,15 @@ def ppo_loss(logits, old_logp, actions, adv, values, returns, masks, clip=0.1, c
     return o
 
 
+def adv_norm(adv, masks):
+    """masked-sample advantage normalisation (extension, parity unpinned: the reference has none)"""
+    a = cf(adv).copy()
+    m = c8(masks)
+    lib().oracle_adv_norm.restype = C.c_long
+    lib().oracle_adv_norm(_p(a, C.c_float), _p(m, C.c_uint8), C.c_long(a.size))
+    return a
+
+
 def clip_grad_norm(g, H, A, max_norm=0.5):
     g = cf(g).copy()
     n = lib().oracle_clip_grad_norm(_p(g, C.c_float), H, A, C.c_float(max_norm))

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(pkg):
 
 
 def test_config_struct_layout_matches_header(pkg):
-    # 12 x int32, 9 x float, pad, uint64 (include/aleppo.h aleppo_config)
+    # 13 x int32, 9 x float, uint64 (include/aleppo.h aleppo_config)
     assert C.sizeof(pkg.Config) == 96 and pkg.Config.seed.offset == 88
     assert C.sizeof(pkg.MinibatchMetrics) == 28
 

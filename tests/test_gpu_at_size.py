@@ -1,0 +1,394 @@
+"""Parity of the PRODUCTION kernels at the sizes the bench runs them (pytest -m gpu, on the MI355X).
+
+tests/test_gpu_parity.py pins every operator against the reference's golden vectors at fixture sizes; here the same
+C-ABI path is checked against the pinned CPU oracle at BASELINE configs[1] size (128 envs x T = 128, 4096-sample
+minibatches, H = 512, bf16) and on the GAE kernel's chunked scan, i.e. the code paths that only engage at size:
+static-atom loops, the register-tiled conv3 dgrad, XCD job maps, the 1-D swizzled fc wgrad launch, the pipelined fc
+GEMMs, 16-step GAE chunks with both register sets.
+
+Bounds.  Integer / byte / index planes and the GAE planes (same fp32 op order): bit-exact.  fp32 network outputs:
+1e-4 (north star).  bf16 operands (8-bit mantissa) with fp32 accumulation: the documented looser bounds are written
+next to each assert; they were set from measured errors on MI355X with ~2x margin.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hashfill as hf
+import oracle_lib as orc
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_package()
+    p.lib()
+    return p
+
+
+class DeviceBytes:
+    """device copy of a numpy array (no torch in the test process)"""
+
+    def __init__(self, arr):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        arr = np.ascontiguousarray(arr)
+        self.ptr = ctypes.c_void_p()
+        assert self.hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(arr.nbytes)) == 0
+        assert self.hip.hipMemcpy(self.ptr, arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(arr.nbytes), 1) == 0
+
+    @property
+    def addr(self):
+        return self.ptr.value
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def _flags(seed, T, E, p_term=0.08, p_trunc=0.04):
+    """slot protocol of SURVEY app. A: a terminated / truncated slot is followed by one episode-start slot"""
+    rng = np.random.default_rng(seed)
+    te = np.zeros((T, E), np.uint8)
+    tr = np.zeros((T, E), np.uint8)
+    st = np.zeros((T, E), np.uint8)
+    start = np.ones(E, np.uint8)
+    for t in range(T):
+        u = rng.random(E)
+        st[t] = start
+        te[t] = ((u < p_term) & (start == 0))
+        tr[t] = ((u >= p_term) & (u < p_term + p_trunc) & (start == 0))
+        start = (te[t] | tr[t]).astype(np.uint8)
+    return te, tr, st
+
+
+# ------------------------------------------------------------------ GAE scan kernel: chunked path inside finish_rollout
+@pytest.mark.parametrize("E,T", [(70, 41), (128, 128), (3, 16), (65, 32), (5, 48), (130, 7)])
+def test_finish_rollout_gae_chunks_vs_oracle(pkg, E, T):
+    """Buffer::get (buffer.cc:58-77) as aleppo_finish_rollout runs it: reward clamp in place, GAE, returns, masks.
+    T = 41: 9-step tail + 2 chunks (both register sets); 128: 8 chunks (the benched shape); 16 / 32 / 48: chunks only
+    with 1 / 2 / 3 loads; 7: tail only; E = 70 / 65 / 130: partial last wave.  Rewards leave [-1, 1] (the clamp acts),
+    flags follow the slot protocol.  Same fp32 op order as the oracle -> bit-exact on OUR stored values."""
+    A, H = 4, 32
+    eng = pkg.Engine(E, T, A, H, precision=pkg.FP32, seed=5)
+    eng.load_params(hf.fill_params(1310, H, A))
+    te, tr, st = _flags(E * 1000 + T, T, E)
+    rew = hf.hf_range(1311, (T, E), -3, 3)
+    frames = DeviceBytes(hf.hf_bytes(1312, (2, E, 84, 84)))  # two alternating frame sets: content is irrelevant here
+    for ro in range(2):  # the second rollout starts from the carried-over slot (state persists across rollouts)
+        for t in range(T):
+            eng.act_fast()
+            eng.step_ptr(frames.addr + (t & 1) * E * 7056, pkg.DEVICE, pkg.FRAMES_84, rew[t].ctypes.data,
+                         te[t].ctypes.data, tr[t].ctypes.data, st[t].ctypes.data)
+        eng.finish_rollout()
+        b = {k: eng.read_batch(k) for k in ("rewards", "values", "next_values", "advantages", "returns", "masks",
+                                            "terminals", "truncations")}
+        o = orc.buffer_get(rew.T, b["values"], b["next_values"], te.T, tr.T, st.T)
+        np.testing.assert_array_equal(b["rewards"], np.clip(rew.T, -1, 1))
+        np.testing.assert_array_equal(b["rewards"], o["rewards"])
+        np.testing.assert_array_equal(b["terminals"], te.T)
+        np.testing.assert_array_equal(b["truncations"], tr.T)
+        np.testing.assert_array_equal(b["masks"], 1 - st.T)
+        np.testing.assert_array_equal(b["advantages"], o["advantages"])
+        np.testing.assert_array_equal(b["returns"], o["returns"])
+        assert np.abs(b["advantages"]).max() > 0
+    frames.free()
+    eng.close()
+
+
+def test_finish_rollout_rejects_overlapping_flags_in_a_chunk(pkg):
+    """gae.cc:49-53 inside the chunked loop (the flag check accumulates into a register there)"""
+    E, T, A, H = 9, 32, 4, 32
+    eng = pkg.Engine(E, T, A, H)
+    eng.load_params(hf.fill_params(1310, H, A))
+    z = np.zeros(E, np.uint8)
+    for t in range(T):
+        eng.act_fast()
+        bad = z.copy()
+        if t == 20:
+            bad[4] = 1
+        eng.step(np.zeros((E, 84, 84), np.uint8), np.zeros(E, np.float32), bad, bad, z if t else np.ones(E, np.uint8))
+    with pytest.raises(pkg.AleppoInvalidArgument, match="mutually exclusive"):
+        eng.finish_rollout()
+    eng.close()
+
+
+# ------------------------------------------------------------------ the benched bf16 update against the oracle
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+@pytest.mark.parametrize("A", [4, 6])
+def test_bf16_update_at_benched_size_vs_oracle(pkg, A):
+    """BASELINE configs[1] minibatch: B = 4096, H = 512, bf16 operands, A = 4 (Breakout) and 6 (Pong): loss, pre-clip
+    gradient norm, EVERY gradient tensor, the per-sample metric planes and the parameters after 1 and after 4
+    optimizer steps against orc.train (fp32) on the same batch.  Every kernel variant that only engages at large B
+    is on this path."""
+    H, N = 512, 4096
+    params = hf.fill_params(1410, H, A)
+    base = hf.hf_bytes(1411, (N // 8, 4, 84, 84))
+    obs = np.concatenate([base ^ np.uint8(29 * k) for k in range(8)])
+    actions = (hf.hf_u32(1412, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(1413, (N, A), -1, 1))
+    adv, ret = hf.hf_range(1414, (N,), -1, 1), hf.hf_range(1415, (N,), -1, 1)
+    masks = (hf.hf_unit(1416, N) >= np.float32(0.05)).astype(np.uint8)
+    eng = pkg.Engine(128, 32, A, H, precision=pkg.BF16)  # E*T = 4096 samples
+    eng.load_params(params)
+    eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+    lr = 2.5e-4  # the reference's learning rate (configs/v0.yaml)
+    offs = orc.param_offsets(H, A)
+    names = ["conv1.w", "conv1.b", "conv2.w", "conv2.b", "conv3.w", "conv3.b", "fc.w", "fc.b", "action.w", "action.b",
+             "value.w", "value.b"]
+    adam, wparams, report, bad = None, params, {}, []
+
+    def check(name, value, bound):
+        report[name] = float(value)
+        if not value <= bound:
+            bad.append((name, float(value), bound))
+
+    for step, epochs in ((1, 1), (4, 3)):
+        m = eng.train(lr, epochs, 1)
+        w = orc.train(wparams, H, A, obs, actions, old_lp, adv, ret, masks, epochs, 1, lr=lr, adam=adam)
+        adam, wparams = w["adam"], w["params"]
+        # scalar loss / pre-clip norm of every step: 1 % relative + 3e-2 absolute on the loss (documented bf16 bound),
+        # 5 % on the norm (measured: 0.1-0.5 % at step 1, 1.4-3 % at step 4)
+        check(f"step{step}_loss", np.max(np.abs(m["loss"] - w["loss"]) - 1e-2 * np.abs(w["loss"])), 3e-2)
+        check(f"step{step}_grad_norm_rel", np.max(np.abs(m["grad_norm"] / w["grad_norm"] - 1)), 5e-2)
+        np.testing.assert_array_equal(m["mask_count"], np.full_like(m["mask_count"], masks.sum()))
+        # per-sample metric planes (Metrics::set, train.h:93-108): |error| <= 5e-2 + 5 % of the value on every sample
+        # (value losses reach ~4 here: a 3e-2 error of v moves 0.5 (v - R)^2 by |v - R| * 3e-2), 1e-2 on the mean
+        for ours, ref in (("total_losses", "total_losses"), ("ratio", "ratio"), ("entropies", "entropies"),
+                          ("value_losses", "value_losses"), ("clipped_losses", "clipped")):
+            got = eng.read_train_metric(ours, epochs, 1, N)
+            err = np.abs(got - w[ref])
+            check(f"step{step}_{ours}_excess", np.max(err - 5e-2 * np.abs(w[ref])), 5e-2)
+            check(f"step{step}_{ours}_mean_excess", err.mean() - 2e-2 * np.abs(w[ref]).mean(), 1e-2)
+        # every gradient tensor of the last minibatch, as clip_grad_norm_ left it: relative L2 error per tensor
+        g, wg = eng.export_grads(), w["last_grads"]
+        cw = min(1.0, 0.5 / (float(w["grad_norm"][-1, -1]) + 1e-6))
+        c0 = min(1.0, 0.5 / (float(m["grad_norm"][-1, -1]) + 1e-6))
+        # measured on MI355X: 0.4-1.7 % per tensor on identical parameters (step 1), 1.3-2.3 % after 4 steps of separate
+        # trajectories; the action head's gradient (policy-gradient terms that nearly cancel: a small norm) 4.4-11.5 % then
+        for k, nm in enumerate(names):
+            bound = 3e-2 if step == 1 else (2.5e-1 if nm.startswith("action") else 5e-2)
+            check(f"step{step}_grad_{nm}_rel", _rel(g[offs[k]:offs[k + 1]] / c0, wg[offs[k]:offs[k + 1]] / cw), bound)
+        check(f"step{step}_grad_all_rel", _rel(g / c0, wg / cw), 2e-2 if step == 1 else 3e-2)
+        # parameters: Adam's first steps move every weight by ~lr whatever the gradient's size, so a bf16 sign flip of
+        # a near-zero gradient entry costs up to 2 lr per step: bound 2.5 lr * steps on the max, lr / 5 * steps on the mean
+        p = eng.export_params()
+        d = np.abs(p - wparams)
+        check(f"step{step}_param_maxabs_over_lr", d.max() / lr, 2.5 * step)
+        check(f"step{step}_param_meanabs_over_lr", d.mean() / lr, 0.2 * step)
+        assert np.abs(p - params).max() > 0.5 * lr
+    print("bf16-at-size report A=%d" % A, {k: round(v, 5) for k, v in report.items()})
+    assert not bad, bad
+    eng.close()
+
+
+# ------------------------------------------------------------------ the bench's rollout path, all together
+def test_replay_rollout_raw_bf16_e128_vs_oracle(pkg):
+    """aleppo_replay_rollout + ALEPPO_FRAMES_RAW_PAIR + bf16 acting + E = 128 (bench.py's rollout leg) against the
+    oracle's planes: observation / flag / reward / action planes bit-exact, logits / values within the bf16 bound of
+    the oracle's fp32 forward, GAE planes bit-exact from OUR values.  T = 24 = 8-step tail + one chunk."""
+    E, T, A, H = 128, 24, 4, 512
+    params = hf.fill_params(1510, H, A)
+    lut = (np.arange(256) // 2 * 2).astype(np.uint8)
+    raw = (hf.hf_bytes(1511, (T, E, 2, 210, 160)) & np.uint8(0xFE))  # ALE palette codes are even
+    dev = DeviceBytes(raw)
+    te, tr, st = _flags(1512, T, E, 0.05, 0.02)
+    rew = np.where(hf.hf_unit(1513, T * E) < np.float32(0.2), hf.hf_range(1514, (T * E,), -4, 7), 0).astype(
+        np.float32).reshape(T, E)
+    noise = np.random.default_rng(1515).exponential(size=(T, E, A)).astype(np.float32)
+    eng = pkg.Engine(E, T, A, H, precision=pkg.BF16, seed=3)
+    eng.load_params(params)
+    eng.set_gray_lut(lut)
+    eng.replay_rollout(dev.addr, pkg.FRAMES_RAW_PAIR, E * 2 * 210 * 160, rew, te, tr, st, noise=noise)
+    eng.finish_rollout(np.random.default_rng(1516).exponential(size=(E, A)).astype(np.float32))
+    b = {k: eng.read_batch(k) for k in pkg.FIELDS if k != "current_obs"}
+    # oracle planes
+    obs_ref = np.zeros((E, 4, 84, 84), np.uint8)
+    obs_all = []
+    for t in range(T):
+        obs_all.append(obs_ref.copy())
+        obs_ref = orc.update_observations(obs_ref, orc.preprocess(raw[t], lut), st[t])
+    obs_em = np.stack(obs_all, 1)
+    np.testing.assert_array_equal(b["observations"], obs_em)
+    np.testing.assert_array_equal(eng.read_batch("current_obs"), obs_ref)
+    np.testing.assert_array_equal(b["terminals"], te.T)
+    np.testing.assert_array_equal(b["truncations"], tr.T)
+    np.testing.assert_array_equal(b["masks"], 1 - st.T)
+    np.testing.assert_array_equal(b["rewards"], np.clip(rew.T, -1, 1))
+    wl, wv = orc.net_forward(params, H, A, obs_em.reshape(E * T, 4, 84, 84))
+    np.testing.assert_allclose(b["logits"].reshape(E * T, A), wl, atol=3e-2)  # bf16 operands: documented bound
+    np.testing.assert_allclose(b["values"].ravel(), wv, atol=3e-2)
+    _, nv = orc.net_forward(params, H, A, obs_ref)
+    np.testing.assert_allclose(b["next_values"], nv, atol=3e-2)
+    want = orc.sample(orc.softmax(b["logits"].reshape(E * T, A)), noise.transpose(1, 0, 2).reshape(E * T, A))
+    np.testing.assert_array_equal(b["actions"].ravel(), want)  # integer indices: bit-exact on ITS logits
+    o = orc.buffer_get(rew.T, b["values"], b["next_values"], te.T, tr.T, st.T)
+    np.testing.assert_array_equal(b["advantages"], o["advantages"])
+    np.testing.assert_array_equal(b["returns"], o["returns"])
+    np.testing.assert_allclose(b["log_probs"].reshape(E * T, A), orc.log_softmax(b["logits"].reshape(E * T, A)),
+                               atol=2e-6)
+    dev.free()
+    eng.close()
+
+
+def test_replay_from_mapped_host_memory_equals_device_frames(pkg):
+    """ALEPPO_HOST_MAPPED: the ingest kernel reads the frames in place from page-locked host memory (the ring the
+    emulator threads would write, rollout.cc:325-326) - same rollout as with the frames resident in HBM"""
+    E, T, A, H = 16, 5, 4, 64
+    hip = ctypes.CDLL("libamdhip64.so")
+    frames = hf.hf_bytes(1611, (T, E, 84, 84))
+    hptr = ctypes.c_void_p()
+    assert hip.hipHostMalloc(ctypes.byref(hptr), ctypes.c_size_t(frames.nbytes), ctypes.c_uint(2)) == 0  # Mapped
+    ctypes.memmove(hptr, frames.ctypes.data, frames.nbytes)
+    dev = DeviceBytes(frames)
+    te, tr, st = _flags(1612, T, E)
+    rew = hf.hf_range(1613, (T, E), -2, 2)
+    got = []
+    for loc, addr in ((pkg.DEVICE, dev.addr), (pkg.HOST_MAPPED, hptr.value)):
+        eng = pkg.Engine(E, T, A, H, precision=pkg.BF16, seed=11)
+        eng.load_params(hf.fill_params(1610, H, A))
+        eng.replay_rollout(addr, pkg.FRAMES_84, E * 7056, rew, te, tr, st, location=loc)
+        eng.finish_rollout()
+        got.append({k: eng.read_batch(k) for k in ("observations", "actions", "values", "advantages", "returns")})
+        eng.close()
+    for k in got[0]:
+        np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=k)
+    np.testing.assert_array_equal(got[0]["observations"][:, 1, 0], frames[0])
+    hip.hipHostFree(hptr)
+    dev.free()
+
+
+# ------------------------------------------------------------------ advantage normalisation (extension; unpinned)
+@pytest.mark.parametrize("E,T", [(6, 9), (128, 32)])
+def test_advantage_norm_extension_vs_oracle(pkg, E, T):
+    """advantage_norm = 1 (NOT in the reference, SURVEY Q2 - off by default; PARITY UNPINNED: checked against the
+    oracle's own definition only): masked mean / unbiased std over the rollout's unmasked samples, applied before the
+    update; returns stay un-normalised."""
+    A, H = 4, 32
+    te, tr, st = _flags(1712, T, E)
+    rew = hf.hf_range(1713, (T, E), -2, 2)
+    frames = DeviceBytes(hf.hf_bytes(1714, (E, 84, 84)))
+    out = []
+    for norm in (False, True):
+        eng = pkg.Engine(E, T, A, H, seed=9, advantage_norm=norm)
+        eng.load_params(hf.fill_params(1710, H, A))
+        for t in range(T):
+            eng.act_fast()
+            eng.step_ptr(frames.addr, pkg.DEVICE, pkg.FRAMES_84, rew[t].ctypes.data, te[t].ctypes.data,
+                         tr[t].ctypes.data, st[t].ctypes.data)
+        eng.finish_rollout()
+        out.append({k: eng.read_batch(k) for k in ("advantages", "returns", "masks")})
+        eng.close()
+    frames.free()
+    plain, normed = out
+    np.testing.assert_array_equal(plain["returns"], normed["returns"])
+    want = orc.adv_norm(plain["advantages"], plain["masks"])
+    np.testing.assert_allclose(normed["advantages"], want, rtol=2e-4, atol=2e-5)
+    sel = normed["advantages"][normed["masks"] != 0]
+    assert abs(sel.mean()) < 1e-4 and abs(sel.std(ddof=1) - 1) < 1e-3
+
+
+def test_advantage_norm_with_every_sample_masked_is_a_no_op(pkg):
+    E, T, A, H = 4, 3, 4, 32
+    eng = pkg.Engine(E, T, A, H, advantage_norm=True)
+    eng.load_params(hf.fill_params(1710, H, A))
+    one, z = np.ones(E, np.uint8), np.zeros(E, np.uint8)
+    for t in range(T):
+        eng.act_fast()
+        eng.step(np.zeros((E, 84, 84), np.uint8), np.zeros(E, np.float32), z, z, one)  # every slot an episode start
+    eng.finish_rollout()
+    a = eng.read_batch("advantages")
+    assert np.isfinite(a).all() and (a == 0).all()
+    eng.close()
+
+
+# ------------------------------------------------------------------ two ranks, real RCCL (needs >= 2 GPUs)
+_DP_SCRIPT = r'''
+import os, sys
+root, rank, idfile, outdir, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import time
+import numpy as np
+import hashfill as hf, oracle_lib as orc
+from __graft_entry__ import load_package
+pkg = load_package()
+WORLD, EG, T, M, H, A = 2, 8, 16, 2, 64, 6
+if rank == 0:
+    open(idfile + ".tmp", "wb").write(pkg.Engine.comm_unique_id()); os.replace(idfile + ".tmp", idfile)
+t0 = time.time()
+while not os.path.exists(idfile):
+    assert time.time() - t0 < 120
+    time.sleep(0.05)
+uid = open(idfile, "rb").read()
+N = WORLD * EG * T
+obs = hf.hf_bytes(1801, (N, 4, 84, 84)); actions = (hf.hf_u32(1802, N) % np.uint32(A)).astype(np.int64)
+old_lp = orc.log_softmax(hf.hf_range(1803, (N, A), -1, 1)); adv = hf.hf_range(1804, (N,), -1, 1)
+ret = hf.hf_range(1805, (N,), -1, 1); masks = (hf.hf_unit(1806, N) >= np.float32(0.25)).astype(np.uint8)
+rows = np.concatenate([np.arange(e * T, (e + 1) * T) for e in pkg.env_shard(WORLD * EG, WORLD, rank)])
+eng = pkg.Engine(EG, T, A, H, precision=pkg.FP32 if mode == "fp32" else pkg.BF16, device=rank, world_size=WORLD,
+                 rank=rank, advantage_norm=False)
+eng.comm_init(uid)
+eng.load_params(hf.fill_params(1810, H, A))
+eng.set_batch(obs[rows], actions[rows], old_lp[rows], adv[rows], ret[rows], masks[rows])
+m = eng.train(1e-3, 2, M)
+np.savez(os.path.join(outdir, f"rank{rank}.npz"), params=eng.export_params(), loss=m["loss"], grad_norm=m["grad_norm"],
+         mask_count=m["mask_count"], grads=eng.export_grads())
+eng.close()
+print("DP_RANK_OK", rank)
+'''
+
+
+def _gpu_count():
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_int(0)
+    return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+
+
+def test_two_rank_rccl_update_equals_one_rank_oracle(tmp_path):
+    """The HIP data-parallel path with REAL RCCL on two GPUs (one process per GPU, started before either touches a
+    device): bucketed gradient all-reduce on the side stream, global mask counts, replicated clip + Adam.  Parity
+    definition of SURVEY 8(e): equals the 1-rank oracle on the batch whose minibatch k concatenates the ranks' local
+    minibatch k; fp32 path, north-star bound 1e-4.  Skips on a one-GPU box."""
+    if _gpu_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the round-end driver's node has 8)")
+    script = tmp_path / "dp_rank.py"
+    script.write_text(_DP_SCRIPT)
+    idfile = str(tmp_path / "nccl_id.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), idfile, str(tmp_path), "fp32"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=420)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"DP_RANK_OK {r}" in o, o[-4000:]
+    WORLD, EG, T, M, H, A = 2, 8, 16, 2, 64, 6
+    N = WORLD * EG * T
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["params"], r1["params"])  # replicated clip + Adam stay in lock-step
+    np.testing.assert_array_equal(r0["grads"], r1["grads"])
+    obs = hf.hf_bytes(1801, (N, 4, 84, 84)); actions = (hf.hf_u32(1802, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(1803, (N, A), -1, 1)); adv = hf.hf_range(1804, (N,), -1, 1)
+    ret = hf.hf_range(1805, (N,), -1, 1); masks = (hf.hf_unit(1806, N) >= np.float32(0.25)).astype(np.uint8)
+    B = EG * T // M
+    order = np.concatenate([np.concatenate([np.arange(r * EG * T + k * B, r * EG * T + (k + 1) * B)
+                                            for r in range(WORLD)]) for k in range(M)])
+    w = orc.train(hf.fill_params(1810, H, A), H, A, obs[order], actions[order], old_lp[order], adv[order], ret[order],
+                  masks[order], 2, M, lr=1e-3)
+    np.testing.assert_allclose(r0["loss"], w["loss"], atol=1e-4)
+    np.testing.assert_allclose(r0["grad_norm"], w["grad_norm"], rtol=1e-3)
+    np.testing.assert_allclose(r0["params"], w["params"], atol=1e-4)
+    np.testing.assert_allclose(r0["mask_count"][0], [masks[order][k * 2 * B:(k + 1) * 2 * B].sum() for k in range(M)])

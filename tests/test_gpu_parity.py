@@ -47,8 +47,20 @@ def test_gae_g1_matches_reference_buffer_get(pkg, golden):
     np.testing.assert_array_equal(adv, orc.gae(np.clip(r, -1, 1), v, nv, te, tr, st))  # same op order: bit-exact
 
 
+def test_gae_does_not_clamp_rewards(pkg):
+    """ai::gae::gae uses the rewards as given (the clamp belongs to Buffer::get, buffer.cc:67): rewards outside [-1, 1]
+    through the same production kernel with its clamp switched off"""
+    r, v, nv, te, tr, st = hf.g1_inputs()
+    assert np.abs(r).max() > 1
+    adv = np.zeros_like(r)
+    pkg.gae.gae(adv, r, v, nv, te, tr, st, 0.99, 0.95)
+    np.testing.assert_array_equal(adv, orc.gae(r, v, nv, te, tr, st))
+
+
 def test_gae_ragged_shapes(pkg):
-    for E, T in [(1, 1), (3, 7), (65, 5), (130, 33)]:
+    # aleppo_gae runs the rollout's gae_kernel: T % 16 steps one at a time, then double-buffered 16-step chunks
+    # (T = 33: 1 + 2 chunks; 48: 3 chunks, both register sets twice; 128 in G1: 8 chunks; 7: tail only)
+    for E, T in [(1, 1), (3, 7), (65, 5), (130, 33), (70, 41), (5, 48), (64, 16), (200, 17)]:
         r = hf.hf_range(11, (E, T), -1, 1)
         v = hf.hf_range(12, (E, T), -1, 1)
         nv = hf.hf_range(13, (E,), -1, 1)
@@ -289,7 +301,6 @@ def test_bf16_patch_kernels_match_generic_kernels(pkg, N):
         eng.set_batch(obs, actions, old_lp, adv, ret, masks)
         m = eng.train(2.5e-4, 1, M)
         res[generic] = (logits, values, m, eng.export_grads(), eng.export_params())
-        eng.set_generic_conv(0)
         eng.close()
     (l1, v1, m1, g1, p1), (l0, v0, m0, g0, p0) = res[1], res[0]
     np.testing.assert_allclose(l0, l1, atol=2e-3)
@@ -311,7 +322,7 @@ def test_bf16_patch_kernels_match_generic_kernels(pkg, N):
 @pytest.mark.parametrize("N,M,H", [(1400, 2, 512), (2048, 2, 512), (4096, 1, 512), (1400, 2, 256), (1024, 1, 320)])
 def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M, H):
     """minibatches > 256 samples route the bf16 fc forward / dgrad through the pipelined LDS-DMA GEMM
-    (gemm_pipe.hpp); ALEPPO_FC_PIPE=0 keeps the small-tile kernels.  Same bf16 operands, fp32 accumulation in a
+    (gemm_pipe.hpp); ALEPPO_OPT_FC_PIPE = 0 keeps the small-tile kernels.  Same bf16 operands, fp32 accumulation in a
     different order (split-K slabs): losses, gradient norm and gradients agree tightly.  700-sample minibatches are
     ragged against the 128-row tiles (identity job map), 1024 / 4096 use the XCD-grouped job map, 4096 gives every
     workgroup several jobs (the ring streams across tile boundaries).  H = 256 is the shortest K the dgrad ring
@@ -324,20 +335,16 @@ def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M, H):
     adv, ret = hf.hf_range(914, (N,), -1, 1), hf.hf_range(915, (N,), -1, 1)
     masks = (hf.hf_unit(916, N) >= np.float32(0.1)).astype(np.uint8)
     res = {}
-    try:
-        for pipe in ("0", "1"):
-            os.environ["ALEPPO_FC_PIPE"] = pipe
-            os.environ["ALEPPO_FC_PIPE_WGRAD"] = pipe  # the opt-in pipelined wgrad (transposed LDS gathers) too
-            eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
-            eng.load_params(params)
-            eng.set_batch(obs, actions, old_lp, adv, ret, masks)
-            m = eng.train(2.5e-4, 2, M)
-            res[pipe] = (m, eng.export_grads(), eng.export_params())
-            eng.close()
-    finally:
-        os.environ.pop("ALEPPO_FC_PIPE", None)
-        os.environ.pop("ALEPPO_FC_PIPE_WGRAD", None)
-    (m0, g0, p0), (m1, g1, p1) = res["0"], res["1"]
+    for pipe in (0, 1):
+        eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
+        eng.set_option(pkg.OPT_FC_PIPE, pipe)        # per-context switches (aleppo_set_option)
+        eng.set_option(pkg.OPT_FC_PIPE_WGRAD, pipe)  # the opt-in pipelined wgrad (transposed LDS gathers) too
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 2, M)
+        res[pipe] = (m, eng.export_grads(), eng.export_params())
+        eng.close()
+    (m0, g0, p0), (m1, g1, p1) = res[0], res[1]
     np.testing.assert_allclose(m1["loss"], m0["loss"], rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(m1["grad_norm"], m0["grad_norm"], rtol=5e-3)
     np.testing.assert_allclose(g1, g0, atol=5e-3 * np.abs(g0).max())
