@@ -208,6 +208,8 @@ static SampleMap slot_map(const Ctx *c, int t) {
 }
 
 static const float *Pf(const Ctx *c, ParamId id) { return c->P + c->L.off[id]; }
+// element i of a rollout plane stored as RT (float or half)
+static void *rp(const Ctx *c, void *plane, size_t i) { return static_cast<char *>(plane) + i * c->rsz; }
 static const void *Pcw(const Ctx *c, ParamId id) {
   return static_cast<const char *>(c->Pc) + c->L.off[id] * tsz(c);
 }
@@ -305,6 +307,8 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   c->world = cfg->world_size;
   c->rank = cfg->rank;
   c->N = (long)c->E * c->T;
+  c->rt16 = cfg->rollout_precision == ALEPPO_ROLLOUT_FP16;
+  c->rsz = c->rt16 ? 2 : 4;
   c->maxB = cfg->max_minibatch > 0 ? std::max<long>(cfg->max_minibatch, c->E) : std::max<long>(c->N, c->E);
   c->L.init(c->H, c->A);
   const int E = c->E, T = c->T, A = c->A, H = c->H;
@@ -332,8 +336,8 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(dalloc(&c->obs, (size_t)E * (T + 1) * FRAME_PIX * 4));
   c->step_rec_bytes = ((size_t)7 * E + 15) / 16 * 16;
   CK(dalloc(&c->step_rec, c->step_rec_bytes * T));
-  CK(dalloc(&c->values_tm, (size_t)(T + 1) * E * 4));
-  CK(dalloc(&c->logits_tm, (size_t)(T + 1) * E * A * 4));
+  CK(dalloc(reinterpret_cast<char **>(&c->values_tm), (size_t)(T + 1) * E * c->rsz));
+  CK(dalloc(reinterpret_cast<char **>(&c->logits_tm), (size_t)(T + 1) * E * A * c->rsz));
   CK(dalloc(&c->actions_tm, (size_t)(T + 1) * E * 4));
   CK(dalloc(&c->lut, 256));
   CK(dalloc(&c->d_start, (size_t)E));
@@ -355,9 +359,9 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_noise), (size_t)E * A * 4, hipHostMallocDefault));
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), 16, hipHostMallocDefault));
   std::memset(c->h_actions, 0, (size_t)(E + 8) * 8);
-  CK(dalloc(&c->adv_n, (size_t)c->N * 4));
-  CK(dalloc(&c->ret_n, (size_t)c->N * 4));
-  CK(dalloc(&c->oldlp_n, (size_t)c->N * A * 4));
+  CK(dalloc(reinterpret_cast<char **>(&c->adv_n), (size_t)c->N * c->rsz));
+  CK(dalloc(reinterpret_cast<char **>(&c->ret_n), (size_t)c->N * c->rsz));
+  CK(dalloc(reinterpret_cast<char **>(&c->oldlp_n), (size_t)c->N * A * c->rsz));
   CK(dalloc(&c->act_n, (size_t)c->N * 4));
   CK(dalloc(&c->mask_n, (size_t)c->N));
   CK(dalloc(&c->mask_counts, 4096 * 4));
@@ -524,7 +528,7 @@ extern "C" int aleppo_import_optimizer(aleppo_ctx *c, const float *exp_avg, cons
 }
 
 // ------------------------------------------------------------------ rollout
-static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst, float *values_dst, int *actions_dst,
+static int do_act(aleppo_ctx *c, const float *noise, int slot, void *logits_dst, void *values_dst, int *actions_dst,
                   bool publish) {
   { // conv stack + split-K fc at acting size; the head kernel finishes the fc reduction
     const SampleMap map = slot_map(c, slot);
@@ -563,7 +567,7 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, float *logits_dst
     pinned_dev = nullptr;
   launch_infer_head(c->stream, c->hpart, FC_SPLITS, Pf(c, P_BFC), Pf(c, P_WH), Pf(c, P_BH), dn, c->cfg.seed,
                     c->rng_counter++, logits_dst, values_dst, actions_dst, pinned_dev, publish ? c->d_done : nullptr,
-                    c->ticket, c->E, c->H, c->A);
+                    c->ticket, c->E, c->H, c->A, nullptr, c->rt16);
   prof_end(c, ALEPPO_K_INFER_HEAD);
   HIPCHK(c, hipGetLastError());
   return ALEPPO_OK;
@@ -578,7 +582,7 @@ extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **act
     c->need_carry = false;
   }
   const size_t o = (size_t)c->t * c->E;
-  int rc = do_act(c, noise, c->t, c->logits_tm + o * c->A, c->values_tm + o, c->actions_tm + o, true);
+  int rc = do_act(c, noise, c->t, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
   if (rc)
     return rc;
   { // wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
@@ -757,7 +761,7 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   const int E = c->E, T = c->T, A = c->A;
   // extra selector call on the post-rollout observation: its values bootstrap slot T-1, its sample is
   // discarded but advances the RNG stream like the reference (rollout.cc:268-270)
-  int rc = do_act(c, noise, T, c->logits_tm + (size_t)T * E * A, c->values_tm + (size_t)T * E,
+  int rc = do_act(c, noise, T, rp(c, c->logits_tm, (size_t)T * E * A), rp(c, c->values_tm, (size_t)T * E),
                   c->actions_tm + (size_t)T * E, false);
   if (rc)
     return rc;
@@ -765,14 +769,14 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   HIPCHK(c, hipMemsetAsync(c->d_err, 0, 4, c->stream));
   prof_begin(c, ALEPPO_K_GAE);
   launch_gae(c->stream, c->step_rec, c->step_rec_bytes, c->values_tm, c->logits_tm, c->actions_tm, c->adv_n, c->ret_n,
-             c->oldlp_n, c->act_n, c->mask_n, c->d_err, E, T, A, c->cfg.gamma, c->cfg.lambda);
+             c->oldlp_n, c->act_n, c->mask_n, c->d_err, E, T, A, c->cfg.gamma, c->cfg.lambda, true, c->rt16);
   prof_end(c, ALEPPO_K_GAE);
   if (c->cfg.advantage_norm) {
-    launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 0);
+    launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 0, c->rt16);
     if ((c->world > 1 || c->force_comm) && c->nccl_comm)
       NCCLCHK(c, ncclAllReduce(c->adv_stats, c->adv_stats, 3, ncclFloat, ncclSum,
                                static_cast<ncclComm_t>(c->nccl_comm), c->stream));
-    launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 1);
+    launch_adv_norm(c->stream, c->adv_n, c->mask_n, c->adv_stats, c->N, 1, c->rt16);
   }
   HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -875,12 +879,13 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const int hparts = net_forward(c, c->obs, map, B, FC_FWD_MAX_PARTS);
       const bool wg_pipe = fc_wgrad_pipelined(prec, B, H); // then the head kernel also emits the fc bias gradient
       prof_begin(c, ALEPPO_K_HEAD);
-      launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, c->oldlp_n + n0 * A, c->adv_n + n0,
-                        c->ret_n + n0, c->mask_n + n0, c->mask_counts + mb, hp, c->dh, prec,
+      launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, rp(c, c->oldlp_n, (size_t)n0 * A),
+                        rp(c, c->adv_n, (size_t)n0), rp(c, c->ret_n, (size_t)n0), c->mask_n + n0, c->mask_counts + mb, hp,
+                        c->dh, prec,
                         c->metric_ps + 0 * fs + (size_t)mi * B, c->metric_ps + 1 * fs + (size_t)mi * B,
                         c->metric_ps + 2 * fs + (size_t)mi * B, c->metric_ps + 3 * fs + (size_t)mi * B,
                         c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr, hparts,
-                        wg_pipe ? sBfc : nullptr);
+                        wg_pipe ? sBfc : nullptr, c->rt16);
       prof_end(c, ALEPPO_K_HEAD);
       if (pack_pending) { // the previous minibatch's repacked dgrad weights
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
@@ -1071,9 +1076,25 @@ extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, cons
     return rc;
   launch_obs_pack(c->stream, c->stage_u8, c->obs, n, train_map(c, 0));
   HIPCHK(c, hipMemcpy(c->act_n, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->oldlp_n, log_probabilities, (size_t)n * c->A * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->adv_n, advantages, (size_t)n * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->ret_n, returns, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (!c->rt16) {
+    HIPCHK(c, hipMemcpy(c->oldlp_n, log_probabilities, (size_t)n * c->A * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->adv_n, advantages, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->ret_n, returns, (size_t)n * 4, hipMemcpyHostToDevice));
+  } else { // half planes: upload as float into the (idle) metric scratch area, round on the device
+    rc = ensure_metric_storage(c, 1, 1, (long)n * std::max(c->A, 1));
+    if (rc)
+      return rc;
+    const struct {
+      const float *src;
+      void *dst;
+      size_t cnt;
+    } pl[3] = {{log_probabilities, c->oldlp_n, (size_t)n * c->A}, {advantages, c->adv_n, (size_t)n}, {returns, c->ret_n, (size_t)n}};
+    for (const auto &q : pl) {
+      HIPCHK(c, hipMemcpy(c->metric_ps, q.src, q.cnt * 4, hipMemcpyHostToDevice));
+      launch_plane_from_float(c->stream, c->metric_ps, q.dst, (long)q.cnt, true);
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+  }
   HIPCHK(c, hipMemcpy(c->mask_n, masks, (size_t)n, hipMemcpyHostToDevice));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->batch_n = n;
@@ -1141,6 +1162,26 @@ extern "C" int aleppo_read_batch(aleppo_ctx *c, int field, void *dst, size_t byt
     launch_transpose_tm_pitched(s, src, pitch, tmp, E, T, inner, elem);
     return fin(tmp);
   };
+  // float planes stored as RT: [count] elements, env-major already (tm = false) or time-major [T][E][inner]
+  auto plane = [&](const void *src, size_t count, bool tm, int inner) -> int {
+    need = count * 4;
+    if (bytes != need)
+      return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: wrong byte count");
+    if (!c->rt16 && !tm)
+      return fin(src);
+    void *em = nullptr;
+    HIPCHK(c, hipMalloc(&tmp, need));
+    if (tm) {
+      HIPCHK(c, hipMalloc(&em, count * c->rsz));
+      launch_transpose_tm_pitched(s, src, (size_t)E * inner * c->rsz, em, E, T, inner, (int)c->rsz);
+      src = em;
+    }
+    launch_plane_to_float(s, src, static_cast<float *>(tmp), (long)count, c->rt16);
+    const int rc2 = fin(tmp);
+    if (em)
+      hipFree(em);
+    return rc2;
+  };
   switch (field) {
   case ALEPPO_F_OBSERVATIONS: {
     need = N * 4 * FRAME_PIX;
@@ -1174,24 +1215,20 @@ extern "C" int aleppo_read_batch(aleppo_ctx *c, int field, void *dst, size_t byt
   case ALEPPO_F_TRUNCATIONS:
     return transposed(c->step_rec + 5 * (size_t)E, c->step_rec_bytes, 1, 1);
   case ALEPPO_F_LOGITS:
-    return transposed(c->logits_tm, (size_t)E * A * 4, A, 4);
+    return plane(c->logits_tm, N * A, true, A);
   case ALEPPO_F_VALUES:
-    return transposed(c->values_tm, (size_t)E * 4, 1, 4);
+    return plane(c->values_tm, N, true, 1);
   case ALEPPO_F_MASKS:
     need = N;
     return fin(c->mask_n);
   case ALEPPO_F_ADVANTAGES:
-    need = N * 4;
-    return fin(c->adv_n);
+    return plane(c->adv_n, N, false, 1);
   case ALEPPO_F_RETURNS:
-    need = N * 4;
-    return fin(c->ret_n);
+    return plane(c->ret_n, N, false, 1);
   case ALEPPO_F_LOG_PROBS:
-    need = N * A * 4;
-    return fin(c->oldlp_n);
+    return plane(c->oldlp_n, N * A, false, A);
   case ALEPPO_F_NEXT_VALUES:
-    need = (size_t)E * 4;
-    return fin(c->values_tm + (size_t)T * E);
+    return plane(rp(c, c->values_tm, (size_t)T * E), (size_t)E, false, 1);
   default:
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: unknown field");
   }

@@ -85,8 +85,11 @@ struct Ctx {
   uint32_t *obs = nullptr;     // [E][T+1][7056] packed stacks; slot T = bootstrap observation
   uint8_t *step_rec = nullptr; // [T] records of { float r[E]; u8 term[E]; u8 trunc[E]; u8 start[E] }
   size_t step_rec_bytes = 0;
-  float *values_tm = nullptr;  // [T+1][E]
-  float *logits_tm = nullptr;  // [T][E][A]
+  // float planes of the rollout buffer are stored as RT = float or IEEE half (cfg.rollout_precision): rt16 / rsz
+  bool rt16 = false;
+  size_t rsz = 4;              // bytes per stored plane element
+  void *values_tm = nullptr;   // RT [T+1][E]
+  void *logits_tm = nullptr;   // RT [T+1][E][A]
   int *actions_tm = nullptr;   // [T][E]
   uint8_t *lut = nullptr;      // [256]
   uint8_t *d_start = nullptr;  // [E] episode-start flags of the slot being ingested
@@ -108,7 +111,7 @@ struct Ctx {
   bool need_carry = false; // copy slot T -> slot 0 before the next rollout's first act
   uint64_t rng_counter = 0;
   // ---- training arrays, env-major n = e*T + t ----
-  float *adv_n = nullptr, *ret_n = nullptr, *oldlp_n = nullptr; // [N], [N], [N][A]
+  void *adv_n = nullptr, *ret_n = nullptr, *oldlp_n = nullptr; // RT [N], [N], [N][A]
   int *act_n = nullptr;
   uint8_t *mask_n = nullptr;
   float *mask_counts = nullptr; // [M_max] global unmasked count per minibatch
@@ -170,21 +173,24 @@ void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t
                    const StartBits *sbits, uint32_t *obs, int E, int slots, int t_src, int t_dst);
 void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, int dst);
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
-                       const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
-                       float *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
-                       int H, int A, const float *probs_in = nullptr);
-void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
-                const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
-                int *err, int E, int T, int A, float gamma, float lambda, bool clamp = true);
+                       const float *bh, const float *noise, uint64_t seed, uint64_t counter, void *logits_t,
+                       void *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
+                       int H, int A, const float *probs_in = nullptr, bool rt16 = false);
+void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const void *values_tm, const void *logits_tm,
+                const int *actions_tm, void *adv_n, void *ret_n, void *oldlp_n, int *act_n, uint8_t *mask_n, int *err,
+                int E, int T, int A, float gamma, float lambda, bool clamp = true, bool rt16 = false);
 
-void launch_adv_norm(hipStream_t s, float *adv_n, const uint8_t *mask_n, float *stats, long n, int phase);
+void launch_adv_norm(hipStream_t s, void *adv_n, const uint8_t *mask_n, float *stats, long n, int phase, bool rt16);
+void launch_plane_to_float(hipStream_t s, const void *src, float *dst, long n, bool rt16);
+void launch_plane_from_float(hipStream_t s, const float *src, void *dst, long n, bool rt16);
 void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long B, int M);
 void launch_head_train(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
-                       const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
+                       const void *oldlp, const void *adv, const void *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
                        long B, int H, int A, float *logits_out, float *values_out, int hparts = 1,
-                       float *slab_bfc = nullptr); // slab_bfc: [nblk][H] column sums of dh (fc bias gradient)
+                       float *slab_bfc = nullptr, // slab_bfc: [nblk][H] column sums of dh (fc bias gradient)
+                       bool rt16 = false);        // oldlp / adv / ret are f16 planes
 struct ReduceSeg {
   const float *slab;
   int S;

@@ -9,6 +9,10 @@
 
 namespace aleppo {
 
+// Rollout-plane storage type RT: float (the reference's Buffer, buffer.cc:12-38) or IEEE half (BASELINE configs[4],
+// "fp16 rollout buffer").  Arithmetic is always fp32: planes are widened on load and rounded (RNE) on store.
+typedef _Float16 f16;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
@@ -144,11 +148,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 // of synchronising the stream, so PCIe write latency overlaps the host's next enqueue.
 // probs_in != nullptr (the stateless aleppo_sample operator, train.cc:374-375 alone): the head is skipped and lane k
 // takes p_k from probs_in[e][k]; the division, the arg-max and the stores are the very same instructions.
-template <int NSPLIT>
+template <int NSPLIT, class RT>
 __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict__ hpart, const float *__restrict__ bfc,
                                                           const float *__restrict__ Wh, const float *__restrict__ bh,
                                                           const float *__restrict__ noise, uint64_t seed,
-                                                          uint64_t counter, float *logits_t, float *values_t,
+                                                          uint64_t counter, RT *logits_t, RT *values_t,
                                                           int *actions_t, int64_t *pinned, unsigned int *done_ctr,
                                                           long long ticket, int E, int H, int A,
                                                           const float *__restrict__ probs_in) {
@@ -243,9 +247,9 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
       }
     }
     if (heads && isact)
-      logits_t[(size_t)e * A + lane] = zmine;
+      logits_t[(size_t)e * A + lane] = (RT)zmine;
     if (heads && lane == A)
-      values_t[e] = zmine;
+      values_t[e] = (RT)zmine;
     if (lane == 0) {
       actions_t[e] = best;
       if (pinned) // system-scope (sc0 sc1, write-through) store straight to the mapped host buffer
@@ -272,13 +276,20 @@ __global__ __launch_bounds__(256) void infer_head_kernel(const float *__restrict
   }
 }
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
-                       const float *bh, const float *noise, uint64_t seed, uint64_t counter, float *logits_t,
-                       float *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
-                       int H, int A, const float *probs_in) {
+                       const float *bh, const float *noise, uint64_t seed, uint64_t counter, void *logits_t,
+                       void *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,
+                       int H, int A, const float *probs_in, bool rt16) {
   (void)nsplit; // always FC_SPLITS on the acting path
-  hipLaunchKernelGGL(infer_head_kernel<FC_SPLITS>, dim3((E + 3) / 4), dim3(256), (size_t)(A + 1) * H * sizeof(float), s,
-                     hpart, bfc, Wh, bh, noise, seed, counter, logits_t, values_t, actions_t, pinned, done_ctr, ticket, E,
-                     H, A, probs_in);
+  const dim3 g((E + 3) / 4), b(256);
+  const size_t sm = (size_t)(A + 1) * H * sizeof(float);
+  if (rt16)
+    hipLaunchKernelGGL((infer_head_kernel<FC_SPLITS, f16>), g, b, sm, s, hpart, bfc, Wh, bh, noise, seed, counter,
+                       static_cast<f16 *>(logits_t), static_cast<f16 *>(values_t), actions_t, pinned, done_ctr, ticket, E,
+                       H, A, probs_in);
+  else
+    hipLaunchKernelGGL((infer_head_kernel<FC_SPLITS, float>), g, b, sm, s, hpart, bfc, Wh, bh, noise, seed, counter,
+                       static_cast<float *>(logits_t), static_cast<float *>(values_t), actions_t, pinned, done_ctr, ticket,
+                       E, H, A, probs_in);
 }
 
 // ================================================================================================
@@ -316,21 +327,16 @@ struct GaeChunk {
   float r[CH], v[CH];
   uint8_t te[CH], tr[CH], st[CH];
 };
-__global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const float *__restrict__ values_tm,
-                                                  const float *__restrict__ logits_tm, const int *__restrict__ actions_tm,
-                                                  float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
-                                                  int *err, int E, int T, int A, float gamma, float lambda, int clamp) {
+template <class RT>
+__global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const RT *__restrict__ values_tm, RT *adv_n,
+                                                  RT *ret_n, uint8_t *mask_n, int *err, int E, int T, float gamma,
+                                                  float lambda, int clamp) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E)
     return;
-  (void)logits_tm;
-  (void)actions_tm;
-  (void)oldlp_n;
-  (void)act_n;
-  (void)A;
   constexpr int CH = GaeChunk::CH;
   const float gl = gamma * lambda;
-  float last = 0.f, nv = values_tm[(size_t)T * E + e];
+  float last = 0.f, nv = (float)values_tm[(size_t)T * E + e];
   int bad = 0;
   auto step = [&](int t, float r, float v, bool bte, bool btr, bool bst) {
     // buffer.cc:67 clamp_, in place (Buffer::get).  clamp == 0: ai::gae::gae alone (the stateless aleppo_gae
@@ -341,8 +347,8 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
     bad |= ((int)bte + (int)btr + (int)bst > 1) ? 1 : 0; // gae.cc:49-53
     const float a = gae_step(rc, v, nv, last, gamma, gl, bst, bte, btr);
     const size_t n = (size_t)e * T + t;
-    adv_n[n] = a;
-    ret_n[n] = a + v;        // buffer.cc:70-71
+    adv_n[n] = (RT)a;        // (the recursion keeps the unrounded fp32 value)
+    ret_n[n] = (RT)(a + v);  // buffer.cc:70-71
     mask_n[n] = bst ? 0 : 1; // buffer.cc:74
     last = a;
     nv = v;
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
       const int t = t1 - 1 - k;
       const uint8_t *fl = rec + (size_t)t * rb + 4 * (size_t)E;
       c.r[k] = reinterpret_cast<const float *>(rec + (size_t)t * rb)[e];
-      c.v[k] = values_tm[(size_t)t * E + e];
+      c.v[k] = (float)values_tm[(size_t)t * E + e];
       c.te[k] = fl[e];
       c.tr[k] = fl[E + e];
       c.st[k] = fl[2 * E + e];
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
   for (int rem = T % CH; rem > 0; --rem) { // the ragged top of the horizon, one step at a time
     const int t = --t1;
     const uint8_t *fl = rec + (size_t)t * rb + 4 * (size_t)E;
-    step(t, reinterpret_cast<const float *>(rec + (size_t)t * rb)[e], values_tm[(size_t)t * E + e], fl[e] != 0,
+    step(t, reinterpret_cast<const float *>(rec + (size_t)t * rb)[e], (float)values_tm[(size_t)t * E + e], fl[e] != 0,
          fl[E + e] != 0, fl[2 * E + e] != 0);
   }
   if (t1 > 0) { // t1 is a multiple of CH (uniform control flow: T is a kernel argument)
@@ -395,7 +401,8 @@ __global__ __launch_bounds__(64) void gae_kernel(uint8_t *rec, size_t rb, const 
 }
 // the embarrassingly parallel part of prepare_batch (train.cc:272-283): old log-probs + actions, one thread
 // per (t, e) slot, written env-major
-__global__ void oldlp_kernel(const float *__restrict__ logits_tm, const int *__restrict__ actions_tm, float *oldlp_n,
+template <class RT>
+__global__ void oldlp_kernel(const RT *__restrict__ logits_tm, const int *__restrict__ actions_tm, RT *oldlp_n,
                              int *act_n, int E, int T, int A) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x; // time-major index t*E + e
   if (i >= (long)E * T)
@@ -403,37 +410,51 @@ __global__ void oldlp_kernel(const float *__restrict__ logits_tm, const int *__r
   const int t = (int)(i / E), e = (int)(i - (long)t * E);
   const size_t n = (size_t)e * T + t;
   act_n[n] = actions_tm[i];
-  const float *z = logits_tm + i * A;
-  float mx = z[0];
+  const RT *z = logits_tm + i * A;
+  float mx = (float)z[0];
   for (int k = 1; k < A; ++k)
-    mx = fmaxf(mx, z[k]);
+    mx = fmaxf(mx, (float)z[k]);
   float s = 0.f;
   for (int k = 0; k < A; ++k)
-    s += expf(z[k] - mx);
+    s += expf((float)z[k] - mx);
   const float lse = mx + logf(s);
   for (int k = 0; k < A; ++k)
-    oldlp_n[n * A + k] = z[k] - lse; // train.cc:279 normalize_logits
+    oldlp_n[n * A + k] = (RT)((float)z[k] - lse); // train.cc:279 normalize_logits
 }
-void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const float *values_tm, const float *logits_tm,
-                const int *actions_tm, float *adv_n, float *ret_n, float *oldlp_n, int *act_n, uint8_t *mask_n,
-                int *err, int E, int T, int A, float gamma, float lambda, bool clamp) {
+template <class RT>
+static void launch_gae_t(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const void *values_tm, const void *logits_tm,
+                         const int *actions_tm, void *adv_n, void *ret_n, void *oldlp_n, int *act_n, uint8_t *mask_n,
+                         int *err, int E, int T, int A, float gamma, float lambda, bool clamp) {
   if (logits_tm) // (the stateless aleppo_gae operator has no logits / actions)
-    hipLaunchKernelGGL(oldlp_kernel, dim3((unsigned)(((long)E * T + 255) / 256)), dim3(256), 0, s, logits_tm, actions_tm,
-                       oldlp_n, act_n, E, T, A);
-  hipLaunchKernelGGL(gae_kernel, dim3((E + 63) / 64), dim3(64), 0, s, step_rec, rec_bytes, values_tm, logits_tm,
-                     actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n, err, E, T, A, gamma, lambda, clamp ? 1 : 0);
+    hipLaunchKernelGGL(oldlp_kernel<RT>, dim3((unsigned)(((long)E * T + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const RT *>(logits_tm), actions_tm, static_cast<RT *>(oldlp_n), act_n, E, T, A);
+  hipLaunchKernelGGL(gae_kernel<RT>, dim3((E + 63) / 64), dim3(64), 0, s, step_rec, rec_bytes,
+                     static_cast<const RT *>(values_tm), static_cast<RT *>(adv_n), static_cast<RT *>(ret_n), mask_n, err,
+                     E, T, gamma, lambda, clamp ? 1 : 0);
+}
+void launch_gae(hipStream_t s, uint8_t *step_rec, size_t rec_bytes, const void *values_tm, const void *logits_tm,
+                const int *actions_tm, void *adv_n, void *ret_n, void *oldlp_n, int *act_n, uint8_t *mask_n, int *err,
+                int E, int T, int A, float gamma, float lambda, bool clamp, bool rt16) {
+  if (rt16)
+    launch_gae_t<f16>(s, step_rec, rec_bytes, values_tm, logits_tm, actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n, err,
+                      E, T, A, gamma, lambda, clamp);
+  else
+    launch_gae_t<float>(s, step_rec, rec_bytes, values_tm, logits_tm, actions_tm, adv_n, ret_n, oldlp_n, act_n, mask_n,
+                        err, E, T, A, gamma, lambda, clamp);
 }
 
 // optional advantage normalisation over unmasked samples (NOT in the reference, Q2; off by default).
 // phase 0: stats[0..2] += {sum, sumsq, count} (one block, deterministic); phase 1: apply.
-__global__ __launch_bounds__(256) void adv_norm_kernel(float *adv, const uint8_t *mask, float *stats, long n, int phase) {
+template <class RT>
+__global__ __launch_bounds__(256) void adv_norm_kernel(RT *adv, const uint8_t *mask, float *stats, long n, int phase) {
   __shared__ float s4[4];
   if (phase == 0) {
     float s = 0.f, q = 0.f, c = 0.f;
     for (long i = threadIdx.x; i < n; i += 256)
       if (mask[i]) {
-        s += adv[i];
-        q += adv[i] * adv[i];
+        const float a = (float)adv[i];
+        s += a;
+        q += a * a;
         c += 1.f;
       }
     s = block_sum_256(s, s4);
@@ -452,12 +473,35 @@ __global__ __launch_bounds__(256) void adv_norm_kernel(float *adv, const uint8_t
     const float var = fmaxf((stats[1] - c * mean * mean) / fmaxf(c - 1.f, 1.f), 0.f);
     const float inv = 1.0f / (sqrtf(var) + 1e-8f);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-      adv[i] = (adv[i] - mean) * inv;
+      adv[i] = (RT)(((float)adv[i] - mean) * inv);
   }
 }
-void launch_adv_norm(hipStream_t s, float *adv_n, const uint8_t *mask_n, float *stats, long n, int phase) {
-  hipLaunchKernelGGL(adv_norm_kernel, dim3(phase == 0 ? 1 : (unsigned)((n + 255) / 256)), dim3(256), 0, s, adv_n,
-                     mask_n, stats, n, phase);
+void launch_adv_norm(hipStream_t s, void *adv_n, const uint8_t *mask_n, float *stats, long n, int phase, bool rt16) {
+  const dim3 g(phase == 0 ? 1 : (unsigned)((n + 255) / 256));
+  if (rt16)
+    hipLaunchKernelGGL(adv_norm_kernel<f16>, g, dim3(256), 0, s, static_cast<f16 *>(adv_n), mask_n, stats, n, phase);
+  else
+    hipLaunchKernelGGL(adv_norm_kernel<float>, g, dim3(256), 0, s, static_cast<float *>(adv_n), mask_n, stats, n, phase);
+}
+
+// boundary conversions of a rollout plane (aleppo_set_batch / aleppo_read_batch)
+template <class S, class D> __global__ void cast_plane_kernel(const S *src, D *dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    dst[i] = (D)(float)src[i];
+}
+void launch_plane_to_float(hipStream_t s, const void *src, float *dst, long n, bool rt16) {
+  const dim3 g((unsigned)std::min<long>((n + 255) / 256, 1024));
+  if (rt16)
+    hipLaunchKernelGGL((cast_plane_kernel<f16, float>), g, dim3(256), 0, s, static_cast<const f16 *>(src), dst, n);
+  else
+    hipLaunchKernelGGL((cast_plane_kernel<float, float>), g, dim3(256), 0, s, static_cast<const float *>(src), dst, n);
+}
+void launch_plane_from_float(hipStream_t s, const float *src, void *dst, long n, bool rt16) {
+  const dim3 g((unsigned)std::min<long>((n + 255) / 256, 1024));
+  if (rt16)
+    hipLaunchKernelGGL((cast_plane_kernel<float, f16>), g, dim3(256), 0, s, src, static_cast<f16 *>(dst), n);
+  else
+    hipLaunchKernelGGL((cast_plane_kernel<float, float>), g, dim3(256), 0, s, src, static_cast<float *>(dst), n);
 }
 
 // unmasked-sample count per minibatch (losses.cc:19 masks.sum()); block per minibatch
@@ -485,11 +529,11 @@ void launch_mask_count(hipStream_t s, const uint8_t *mask_n, float *counts, long
 // ================================================================================================
 // Wide action sets (AMAX = 18: 19 x 8 wgrad accumulators per lane) run 4 waves per workgroup: one wave per SIMD may
 // use the whole 512-entry register file; with 8 waves the 256-register cap spilled the accumulators (150 us vs 22).
-template <class T, int AMAX>
+template <class T, int AMAX, class RT>
 __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
     const float *__restrict__ h, const float *__restrict__ Wh, const float *__restrict__ bh,
-    const int *__restrict__ act, const float *__restrict__ oldlp, const float *__restrict__ adv,
-    const float *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
+    const int *__restrict__ act, const RT *__restrict__ oldlp, const RT *__restrict__ adv,
+    const RT *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
     T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
     float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc) {
   constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
@@ -527,10 +571,10 @@ __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
     }
 #pragma unroll
     for (int a = 0; a < AMAX; ++a)
-      olp_n[a] = (ok && a < A) ? oldlp[(size_t)r * A + a] : 0.f;
+      olp_n[a] = (ok && a < A) ? (float)oldlp[(size_t)r * A + a] : 0.f;
     act_n = ok ? act[r] : 0;
-    adv_n = ok ? adv[r] : 0.f;
-    ret_n = ok ? ret[r] : 0.f;
+    adv_n = ok ? (float)adv[r] : 0.f;
+    ret_n = ok ? (float)ret[r] : 0.f;
     mask_n = ok ? mask[r] != 0 : false;
   };
   fetch(row0 + wave);
@@ -741,9 +785,9 @@ __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
   }
 }
 
-template <class T>
+template <class T, class RT>
 static void head_train_t(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
-                         const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
+                         const RT *oldlp, const RT *adv, const RT *ret, const uint8_t *mask,
                          const float *mask_count, Hyper hp, void *dh, float *ps_total, float *ps_clipped,
                          float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
                          long B, int H, int A, float *lo, float *vo, int hparts, float *slab_bfc) {
@@ -751,9 +795,9 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
   do {                                                                                                                 \
     const size_t sm = ((size_t)((AM + 1) + ((AM + 1) > 8 ? (AM + 1) : 8)) * H + 8 * (AM + 1)) * sizeof(float);        \
     if (sm > 48 * 1024)                                                                                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&head_train_kernel<T, AM>),                             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&head_train_kernel<T, AM, RT>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
-    hipLaunchKernelGGL((head_train_kernel<T, AM>), dim3(nblk), dim3(AM > 10 ? 256 : 512), sm, s, h, Wh, bh, act, oldlp, adv, ret,      \
+    hipLaunchKernelGGL((head_train_kernel<T, AM, RT>), dim3(nblk), dim3(AM > 10 ? 256 : 512), sm, s, h, Wh, bh, act, oldlp, adv, ret,  \
                        mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
                        ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts, slab_bfc);                                         \
   } while (0)
@@ -768,16 +812,27 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
 #undef LAUNCH_HEAD
 }
 void launch_head_train(hipStream_t s, const float *h, const float *Wh, const float *bh, const int *act,
-                       const float *oldlp, const float *adv, const float *ret, const uint8_t *mask,
+                       const void *oldlp, const void *adv, const void *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                       long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc) {
-  if (prec == ALEPPO_BF16)
-    head_train_t<bf16>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
-                       ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts, slab_bfc);
-  else
-    head_train_t<float>(s, h, Wh, bh, act, oldlp, adv, ret, mask, mask_count, hp, dh, ps_total, ps_clipped, ps_value,
-                        ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A, logits_out, values_out, hparts, slab_bfc);
+                       long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc,
+                       bool rt16) {
+#define HEAD_ARGS(RT)                                                                                                  \
+  s, h, Wh, bh, act, static_cast<const RT *>(oldlp), static_cast<const RT *>(adv), static_cast<const RT *>(ret), mask, \
+      mask_count, hp, dh, ps_total, ps_clipped, ps_value, ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A,         \
+      logits_out, values_out, hparts, slab_bfc
+  if (prec == ALEPPO_BF16) {
+    if (rt16)
+      head_train_t<bf16, f16>(HEAD_ARGS(f16));
+    else
+      head_train_t<bf16, float>(HEAD_ARGS(float));
+  } else {
+    if (rt16)
+      head_train_t<float, f16>(HEAD_ARGS(f16));
+    else
+      head_train_t<float, float>(HEAD_ARGS(float));
+  }
+#undef HEAD_ARGS
 }
 
 // ================================================================================================

@@ -49,15 +49,61 @@ def log(msg):
     sys.stderr.flush()
 
 
+def kernel_source_stamp():
+    """sha256 (16 hex digits) over the kernel sources: a recorded PMC traffic figure is only quoted for the kernels it
+    was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ale-libtorch-ppo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class MappedHost:
+    """page-locked host memory the GPU can address (hipHostMallocMapped): what a ring filled by emulator threads looks
+    like to the device.  No torch / GPU state is needed to allocate it."""
+
+    def __init__(self, nbytes):
+        import ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ptr = ctypes.c_void_p()
+        rc = self.hip.hipHostMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(nbytes), ctypes.c_uint(2))
+        if rc != 0:
+            raise RuntimeError(f"hipHostMalloc({nbytes}) failed: {rc}")
+        self.nbytes = nbytes
+
+    def fill_from(self, arr):
+        import ctypes
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes == self.nbytes
+        ctypes.memmove(self.ptr, arr.ctypes.data, arr.nbytes)
+
+    @property
+    def addr(self):
+        return self.ptr.value
+
+    def free(self):
+        self.hip.hipHostFree(self.ptr)
+
+
 def run(args):
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` outside a launcher: start the one-process-per-GPU job ourselves, as a CHILD and
+            # before this process has touched a GPU, and leave with its exit code
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + \
+                  sys.argv[1:]
+            log("spawning: " + " ".join(cmd))
+            raise SystemExit(subprocess.call(cmd))
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -66,8 +112,9 @@ def run(args):
     E, T, A, H = args.envs, args.horizon, args.actions, 512
     epochs, M = args.epochs, args.minibatches
     prec = pkg.BF16 if args.dtype == "bf16" else pkg.FP32
+    rollp = pkg.ROLLOUT_FP16 if args.rollout_fp16 else pkg.ROLLOUT_FP32
     eng = pkg.Engine(E, T, A, H, precision=prec, device=local_rank, world_size=world, rank=rank, seed=42 + rank,
-                     max_minibatch=E * T // M)
+                     max_minibatch=E * T // M, rollout_precision=rollp)
     if world > 1:
         uid = [pkg.Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -211,10 +258,17 @@ def run(args):
                             frac=round(max(t_hbm, t_mfma) / (ms * 1e-3), 4))
         dom = max(table, key=lambda k: trn[k][0] * trn[k][1])
         d = table[dom]
-        pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.dtype == "bf16" and B == 4096:
-            pmc = json.load(open(pmc_path)).get(dom)
+        # HBM traffic of the dominant kernel: recorded by `tests/tools/pmc_traffic.py` (rocprofv3 --pmc passes cannot run
+        # inside this process).  The record carries the hash of the kernel sources it was measured on; a record from
+        # other sources is NOT quoted (traffic = null).
+        pmc, pmc_file = None, None
+        stamp = kernel_source_stamp()
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if name.endswith("_pmc_traffic.json") and args.dtype == "bf16" and B == 4096:
+                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if rec.get("kernel_source_sha16") == stamp and dom in rec:
+                    pmc, pmc_file = rec[dom], name
+                    break
         if d["bound"] == "hbm":
             roofline = dict(bound="hbm", kernel=dom, achieved=d["GBps"], peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=round(d["GBps"] / PEAK_HBM_GBS, 4),
@@ -225,8 +279,9 @@ def run(args):
                             frac=round(d["TFLOPs"] / peak_tf, 4), traffic=(pmc["traffic_MB"] * 1e6 if pmc else None),
                             flop_per_launch=KFLOP[dom] * B)
         roofline.update(avg_launch_ms=round(trn[dom][0], 4), launches=trn[dom][1],
-                        traffic_source="profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                       "FETCH x2 gfx950 correction)" if pmc else None)
+                        traffic_recorded_in=(f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                                             f"passes, FETCH x2 gfx950 correction; kernel sources {stamp})") if pmc
+                        else None, kernel_source_sha16=stamp)
         upd_ms = sum(v[0] * v[1] for v in trn.values())
         roofline["update_all_kernels_TFLOPs"] = round(sum(KFLOP.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e12, 2)
         roofline["update_all_kernels_GBps"] = round(sum(KB.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e9, 1)
@@ -263,10 +318,47 @@ def run(args):
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f"v1-shape leg failed: {e}\n")
 
+    # ---- the SAME workload with the frames where a host emulator leaves them (rollout.cc:325-326): page-locked host
+    # memory the ingest kernel reads in place over PCIe (ALEPPO_HOST_MAPPED).  Reported beside `value`, never as it.
+    host_legs = None
+    if rank == 0 and world == 1 and not args.no_host_legs:
+        host_legs = {}
+        hsteps = max(2, min(args.steps, 5))
+        for leg, kind, per_env in (("frames_84_mapped_host", pkg.FRAMES_84, 84 * 84),
+                                   ("raw_pair_mapped_host", pkg.FRAMES_RAW_PAIR, 2 * 210 * 160)):
+            try:
+                mh = MappedHost(T * E * per_env)
+                if kind == pkg.FRAMES_RAW_PAIR:
+                    mh.fill_from(frames.cpu().numpy())
+                else:
+                    mh.fill_from(np.random.default_rng(7).integers(0, 256, (T, E, 84, 84), dtype=np.uint8))
+                rs = 0
+                plan_j = 0
+                for i in range(1 + hsteps):
+                    rew, te, tr, st = plans[plan_j % len(plans)]
+                    plan_j += 1
+                    if i == 1:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    eng.replay_rollout(mh.addr, kind, E * per_env, rew, te, tr, st, location=pkg.HOST_MAPPED)
+                    eng.finish_rollout()
+                    eng.train(2.5e-4, epochs, M)
+                    if i >= 1:
+                        rs += int((st == 0).sum())
+                torch.cuda.synchronize()
+                hdt = time.perf_counter() - t0
+                mh.free()
+                host_legs[leg] = {"value": round(rs / hdt, 1), "unit": "env-steps/s", "steps": hsteps,
+                                  "ms_per_step": round(hdt / hsteps * 1e3, 3),
+                                  "pcie_bytes_per_slot": E * per_env}
+                log(f"host leg {leg}: {rs / hdt:.0f} env-steps/s")
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"host-frames leg {leg} failed: {e}\n")
+
     # ---- CPU baseline beside it (rank 0, N=1 only): the reference's own compiled CPU-libtorch path
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(E, T, A, epochs, M)
 
     if rank == 0:
         out = {
@@ -277,8 +369,9 @@ def run(args):
             "config": {"workload": f"Breakout-shaped synthetic, {E} envs/GPU x T={T}, A={A}, H=512, "
                                    f"{epochs} epochs x {M} minibatches of {E * T // M} (configs[1], v0.yaml update shape)",
                        "envs_per_gpu": E, "horizon": T, "epochs": epochs, "minibatches": M,
-                       "parallelism": f"dp{world}", "frames": "raw u8 [E,2,210,160] pairs resident in HBM"},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "parallelism": f"dp{world}", "frames": "raw u8 [E,2,210,160] pairs resident in HBM",
+                       "rollout_planes": "fp16" if args.rollout_fp16 else "fp32"},
+            "roofline": roofline, "cpu_baseline": cpu, "host_frames": host_legs,
             "vs_reference_published_v1_26289": round(value / 26289.0, 2), "v1_shape": v1,
             "last_loss": float(metrics["loss"][-1, -1]), "last_grad_norm": float(metrics["grad_norm"][-1, -1]),
         }
@@ -332,36 +425,52 @@ def v1_shape_leg(pkg, args, device):
             "vs_reference_published_v1_26289": round(E * T * steps / dt / 26289.0, 2)}
 
 
-def cpu_baseline():
-    """time oracle/_ref/ref_harness (the reference's compiled gae.cc/buffer.cc/losses.cc/train.{h,cc} on
-    CPU libtorch) on a bounded sample: configs/v0.yaml shape (8 envs, T=128, 4 epochs x 4 minibatches)."""
+def cpu_baseline(E, T, A, epochs, M):
+    """time oracle/_ref/ref_harness (the reference's own gae.cc / buffer.cc / losses.cc / train.{h,cc} compiled against
+    CPU libtorch) on the GPU box's host cores, on a bounded sample of the SAME workload as `value` (same envs, horizon,
+    minibatches: one rollout + update after one warm-up, ~20-40 s), with the reference's own configs/v0.yaml shape
+    (8 envs) beside it."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     # the GPU box gives one GPU a share of 16 host cores; never oversubscribe beyond the affinity mask
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))
     log(f"cpu baseline: reference harness on {threads} threads")
+
+    def harness(e, t, a, ep, m, iters):
+        out = subprocess.run([exe, "bench", str(e), str(t), "512", str(a), str(ep), str(m), str(iters), str(threads)],
+                             check=True, capture_output=True, text=True, timeout=400).stdout.strip().splitlines()[-1]
+        return json.loads(out)
+
     if os.path.exists(exe):
         try:
-            out = subprocess.run([exe, "bench", "8", "128", "512", "4", "4", "4", "24", str(threads)], check=True,
-                                 capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1]
-            j = json.loads(out)
-            return {"value": round(j["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": threads,
-                    "kind": "reference",
-                    "sample": "configs/v0.yaml shape: 8 envs x T=128, 4 epochs x 4 minibatches of 256, H=512, "
-                              f"24 rollouts+updates after 1 warm-up ({j['seconds']:.1f} s), libtorch CPU"}
+            j = harness(E, T, A, epochs, M, 1)
+            res = {"value": round(j["env_steps_per_s"], 1), "unit": "env-steps/s", "cores": threads,
+                   "kind": "reference",
+                   "sample": f"the workload of `value`: {E} envs x T={T}, {epochs} epochs x {M} minibatches of "
+                             f"{E * T // M}, H=512, A={A}; 1 rollout+update after 1 warm-up ({j['seconds']:.1f} s), "
+                             "libtorch CPU, pre-resized 84x84 frames"}
+            try:
+                v0 = harness(8, 128, 4, 4, 4, 12)
+                res["v0_yaml_shape"] = {"value": round(v0["env_steps_per_s"], 1), "unit": "env-steps/s",
+                                        "sample": "configs/v0.yaml: 8 envs x T=128, 4 epochs x 4 minibatches of 256; "
+                                                  f"12 rollouts+updates after 1 warm-up ({v0['seconds']:.1f} s)"}
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"v0-shape cpu point failed: {e}\n")
+            return res
         except Exception as e:  # noqa: BLE001
             sys.stderr.write(f"reference cpu baseline failed ({e}); falling back to the C port\n")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hashfill as hf
     import oracle_lib as orc
-    H, A, N, M, ep = 512, 4, 256, 4, 1
+    H, N, Mp, ep = 512, 1024, 1, 1
     params = hf.fill_params(310, H, A)
     obs = hf.hf_bytes(5, (N, 4, 84, 84))
     t0 = time.perf_counter()
     orc.train(params, H, A, obs, np.zeros(N, np.int64), orc.log_softmax(np.zeros((N, A), np.float32)),
-              np.ones(N, np.float32), np.ones(N, np.float32), np.ones(N, np.uint8), ep, M)
+              np.ones(N, np.float32), np.ones(N, np.float32), np.ones(N, np.uint8), ep, Mp)
     dt = time.perf_counter() - t0
-    return {"value": round(N / dt / 4, 1), "unit": "env-steps/s", "cores": orc.lib().oracle_num_threads(),
-            "kind": "port", "sample": "oracle C port: 256 samples x 1 epoch update, scaled to 4 epochs"}
+    return {"value": round(N / dt / epochs, 1), "unit": "env-steps/s", "cores": orc.lib().oracle_num_threads(),
+            "kind": "port", "sample": f"oracle C port: {N}-sample x 1 epoch update, scaled to {epochs} epochs "
+                                      "(update only; acting forward not included)"}
 
 
 if __name__ == "__main__":
@@ -379,4 +488,8 @@ if __name__ == "__main__":
     ap.add_argument("--python-slot-loop", action="store_true",
                     help="drive the per-slot act/step loop from Python instead of aleppo_replay_rollout")
     ap.add_argument("--no-v1", action="store_true", help="skip the secondary v1.yaml-shape leg")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the frames-in-pinned-host-memory legs")
+    ap.add_argument("--rollout-fp16", action="store_true",
+                    help="BASELINE configs[4]: half-precision rollout planes (use with --envs 256 --actions 6)")
+    ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py spawns the ranks")
     run(ap.parse_args())

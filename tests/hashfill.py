@@ -9,6 +9,8 @@ _M = np.uint32(0xFFFFFFFF)
 
 
 def hf_u32(seed, n_or_idx):
+    if isinstance(n_or_idx, tuple):
+        raise TypeError("hf_u32 / hf_unit take a count or an index array, not a shape: use hf_range / reshape")
     idx = np.arange(n_or_idx, dtype=np.uint32) if np.isscalar(n_or_idx) else np.asarray(n_or_idx, dtype=np.uint32)
     with np.errstate(over="ignore"):
         x = idx * np.uint32(0x9E3779B1) + np.uint32(seed) * np.uint32(0x85EBCA77) + np.uint32(0x165667B1)

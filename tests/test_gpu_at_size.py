@@ -310,6 +310,89 @@ def test_advantage_norm_with_every_sample_masked_is_a_no_op(pkg):
     eng.close()
 
 
+# ------------------------------------------------------------------ configs[4]: fp16 rollout buffer + mixed precision
+def _h(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def test_fp16_rollout_buffer_mixed_precision_vs_oracle(pkg):
+    """BASELINE configs[4] per-GPU shape: E_g = 256 envs, A = 6 (SpaceInvaders), rollout_precision = FP16 (values,
+    logits, advantages, returns, old log-probs stored as IEEE half; the reference's Buffer holds f32 planes,
+    buffer.cc:12-38) with the bf16 / fp32-master update.  Oracle planes = the oracle's fp32 arithmetic on the
+    half-rounded inputs, rounded to half where the library stores: GAE planes bit-exact (same op order, RNE both
+    sides), log-probs within one half ulp, network outputs within the bf16 bound, update within the bf16 bound."""
+    E, T, A, H = 256, 16, 6, 512
+    params = hf.fill_params(1910, H, A)
+    frames = hf.hf_bytes(1911, (T, E, 84, 84))
+    dev = DeviceBytes(frames)
+    te, tr, st = _flags(1912, T, E, 0.05, 0.02)
+    rew = hf.hf_range(1913, (T, E), -2, 2)
+    noise = np.random.default_rng(1915).exponential(size=(T, E, A)).astype(np.float32)
+    eng = pkg.Engine(E, T, A, H, precision=pkg.BF16, rollout_precision=pkg.ROLLOUT_FP16, seed=3)
+    eng.load_params(params)
+    eng.replay_rollout(dev.addr, pkg.FRAMES_84, E * 7056, rew, te, tr, st, noise=noise)
+    eng.finish_rollout(np.random.default_rng(1916).exponential(size=(E, A)).astype(np.float32))
+    b = {k: eng.read_batch(k) for k in pkg.FIELDS if k != "current_obs"}
+    for k in ("values", "logits", "advantages", "returns", "log_probs", "next_values"):
+        np.testing.assert_array_equal(b[k], _h(b[k]), err_msg=f"{k} is not a half-precision plane")
+    obs_ref = np.zeros((E, 4, 84, 84), np.uint8)
+    obs_all = []
+    for t in range(T):
+        obs_all.append(obs_ref.copy())
+        obs_ref = orc.update_observations(obs_ref, frames[t], st[t])
+    obs_em = np.stack(obs_all, 1)
+    np.testing.assert_array_equal(b["observations"], obs_em)
+    wl, wv = orc.net_forward(params, H, A, obs_em.reshape(E * T, 4, 84, 84))
+    np.testing.assert_allclose(b["logits"].reshape(E * T, A), wl, atol=3e-2)  # bf16 operands + half storage
+    np.testing.assert_allclose(b["values"].ravel(), wv, atol=3e-2)
+    # actions were sampled from the fp32 logits BEFORE they were rounded for storage: check in-range and that the
+    # stored half logits give the same action wherever the arg-max margin exceeds the rounding (tie-margin filter)
+    sc = orc.softmax(b["logits"].reshape(E * T, A)) / noise.transpose(1, 0, 2).reshape(E * T, A)
+    top = np.sort(sc, 1)
+    clear = top[:, -1] > top[:, -2] * 1.01
+    assert clear.mean() > 0.9
+    np.testing.assert_array_equal(b["actions"].ravel()[clear], sc.argmax(1)[clear])
+    o = orc.buffer_get(rew.T, b["values"], b["next_values"], te.T, tr.T, st.T)
+    np.testing.assert_array_equal(b["advantages"], _h(o["advantages"]))
+    np.testing.assert_array_equal(b["returns"], _h(o["returns"]))
+    lp = orc.log_softmax(b["logits"].reshape(E * T, A))
+    np.testing.assert_allclose(b["log_probs"].reshape(E * T, A), lp, atol=2e-3, rtol=1e-3)  # one half ulp
+    # mixed-precision update on the half planes vs the oracle's fp32 update on the same (rounded) batch
+    m = eng.train(2.5e-4, 1, 1)
+    w = orc.train(params, H, A, obs_em.reshape(E * T, 4, 84, 84), b["actions"].ravel(), b["log_probs"].reshape(E * T, A),
+                  b["advantages"].ravel(), b["returns"].ravel(), b["masks"].ravel(), 1, 1)
+    np.testing.assert_allclose(m["loss"], w["loss"], rtol=1e-2, atol=3e-2)
+    np.testing.assert_allclose(m["grad_norm"], w["grad_norm"], rtol=5e-2)
+    g, wg = eng.export_grads(), w["last_grads"]
+    cw = min(1.0, 0.5 / (float(w["grad_norm"][-1, -1]) + 1e-6))
+    c0 = min(1.0, 0.5 / (float(m["grad_norm"][-1, -1]) + 1e-6))
+    assert _rel(g / c0, wg / cw) < 3e-2
+    dev.free()
+    eng.close()
+
+
+def test_fp16_rollout_planes_set_batch_round_trip(pkg):
+    """aleppo_set_batch into half planes rounds to nearest-even; the fp32 update path reads them back widened"""
+    E, T, A, H = 8, 8, 4, 32
+    N = E * T
+    eng = pkg.Engine(E, T, A, H, rollout_precision=pkg.ROLLOUT_FP16)
+    eng.load_params(hf.fill_params(1920, H, A))
+    obs = hf.hf_bytes(1921, (N, 4, 84, 84))
+    actions = (hf.hf_u32(1922, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(1923, (N, A), -1, 1))
+    adv, ret = hf.hf_range(1924, (N,), -1, 1), hf.hf_range(1925, (N,), -1, 1)
+    masks = (hf.hf_unit(1926, N) >= np.float32(0.1)).astype(np.uint8)
+    eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+    np.testing.assert_array_equal(eng.read_batch("advantages").ravel(), _h(adv))
+    np.testing.assert_array_equal(eng.read_batch("returns").ravel(), _h(ret))
+    np.testing.assert_array_equal(eng.read_batch("log_probs").reshape(N, A), _h(old_lp))
+    m = eng.train(2.5e-4, 1, 2)
+    w = orc.train(hf.fill_params(1920, H, A), H, A, obs, actions, _h(old_lp), _h(adv), _h(ret), masks, 1, 2)
+    np.testing.assert_allclose(m["loss"], w["loss"], atol=1e-4)  # fp32 network on the rounded planes: north-star bound
+    np.testing.assert_allclose(eng.export_params(), w["params"], atol=1e-4)
+    eng.close()
+
+
 # ------------------------------------------------------------------ two ranks, real RCCL (needs >= 2 GPUs)
 _DP_SCRIPT = r'''
 import os, sys

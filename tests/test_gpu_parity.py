@@ -162,7 +162,7 @@ def test_sampling_and_losses_wide_action_sets_vs_oracle(pkg, A):
     terms and gradients to 1e-5 / 1e-6.  A = 1 is the degenerate single-action policy."""
     E, B = 333, 200
     probs = orc.softmax(hf.hf_range(960 + A, (E, A), -3, 3))
-    q = np.maximum(hf.hf_unit(961 + A, (E, A)), np.float32(1e-7))
+    q = np.maximum(hf.hf_unit(961 + A, E * A).reshape(E, A), np.float32(1e-7))
     np.testing.assert_array_equal(pkg.sampling.multinomial_with_noise(probs, q), orc.sample(probs, q))
     logits = hf.hf_range(962 + A, (B, A), -2, 2)
     actions = (hf.hf_u32(963 + A, B) % np.uint32(A)).astype(np.int64)

@@ -1,9 +1,9 @@
-"""Build profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes over tests/tools/kbench.py (developer tool).
+"""Build profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes over tests/tools/kbench.py (developer tool).
 
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o p --output-format csv -- python3 tests/tools/kbench.py
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o p --output-format csv -- python3 tests/tools/kbench.py
     rocprofv3 --kernel-trace --stats -d gpurun_out/kt -o p --output-format csv -- python3 tests/tools/kbench.py
-    python tests/tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/kt > profiles/r01_pmc_traffic.json
+    python tests/tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/kt > profiles/r02_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB per the guide's HBM section; FETCH_SIZE is doubled on gfx950 (its correction).
 Per-launch means; kernels are mapped to the bench's kernel classes by name.
@@ -56,4 +56,12 @@ for c in fetch:
     out[c] = {"launches": n[c], "avg_us": round(us, 1) if us else None, "fetch_MB": round(fm, 1), "write_MB": round(wm, 1),
               "traffic_MB": round(fm + wm, 1), "algorithmic_MB": ALGO_MB.get(c),
               "GBps": round((fm + wm) * 1e6 / (us * 1e-6) / 1e9, 1) if us else None}
+# stamp with the kernel sources the counters were taken on: bench.py quotes the record only for the same sources
+import hashlib
+_h = hashlib.sha256()
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "ale-libtorch-ppo_amd", "csrc")
+for _f in sorted(os.listdir(_d)):
+    if _f.endswith((".hip", ".hpp")):
+        _h.update(open(os.path.join(_d, _f), "rb").read())
+out["kernel_source_sha16"] = _h.hexdigest()[:16]
 print(json.dumps(out, indent=1))
