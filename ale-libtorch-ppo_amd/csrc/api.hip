@@ -32,7 +32,8 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fc_pipe_wgrad = flag("ALEPPO_FC_PIPE_WGRAD", false);
-  t.fused_act = flag("ALEPPO_FUSED_ACT", true);
+  if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
+    t.fused_act = std::atoi(e);
   return t;
 }
 const Tuning &tuning() {
@@ -476,6 +477,7 @@ extern "C" int aleppo_load_params(aleppo_ctx *c, const float *flat, size_t count
   HIPCHK(c, hipMemset(c->M2, 0, tmp.size() * 4));
   HIPCHK(c, hipMemset(c->G, 0, tmp.size() * 4));
   c->adam_step = 0;
+  c->pre_acted = -1;
   refresh_compute_copies(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ALEPPO_OK;
@@ -530,7 +532,7 @@ extern "C" int aleppo_import_optimizer(aleppo_ctx *c, const float *exp_avg, cons
 // ------------------------------------------------------------------ rollout
 static int do_act(aleppo_ctx *c, const float *noise, int slot, void *logits_dst, void *values_dst, int *actions_dst,
                   bool publish) {
-  { // conv stack + split-K fc at acting size; the head kernel finishes the fc reduction
+  if (c->pre_acted != slot) { // conv stack + split-K fc at acting size; the head kernel finishes the fc reduction
     const SampleMap map = slot_map(c, slot);
     if (c->prec == ALEPPO_BF16 && use_patch_kernels()) { // one launch: a1/a2 never leave LDS
       prof_begin(c, ALEPPO_K_CONV1_FWD);
@@ -552,6 +554,7 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, void *logits_dst,
     fc_fwd_splitk(c->stream, c->prec, c->a3, Pcw(c, P_WFC), c->hpart, c->E, c->H);
     prof_end(c, ALEPPO_K_FC_FWD);
   }
+  c->pre_acted = -1; // (consumed; a3 / hpart are scratch again)
   const float *dn = nullptr;
   if (noise) {
     std::memcpy(c->h_noise, noise, (size_t)c->E * c->A * 4);
@@ -648,6 +651,7 @@ static int do_push(aleppo_ctx *c, const uint8_t *frames, int kind, int location,
   int rc = upload_frames(c, frames, kind, location, &df);
   if (rc)
     return rc;
+  c->pre_acted = -1;
   prof_begin(c, ALEPPO_K_INGEST);
   launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, c->d_start, nullptr, c->obs, c->E, c->T + 1,
                 c->t, c->t + 1);
@@ -713,10 +717,33 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
   int rc = upload_frames(c, frames, kind, location, &df);
   if (rc)
     return rc;
-  prof_begin(c, ALEPPO_K_INGEST);
-  launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, nullptr, &sb, c->obs, E, c->T + 1, c->t,
-                c->t + 1);
-  prof_end(c, ALEPPO_K_INGEST);
+  // Fused ingest pays for given 84x84 frames (15.7 -> 14.4 ms per 128-slot rollout+update with the frames in mapped host
+  // memory) and for raw pairs read over the bus (one environment's pair is staged by ONE workgroup with nine 16-byte
+  // loads per thread in flight).  Raw pairs resident in HBM stay on the stand-alone ingest kernel: there the palette
+  // lookups of 67 K source bytes per environment are spread over all 256 CUs instead of the 128 acting workgroups
+  // (measured: 5.01 vs 5.10 ms per rollout).
+  const bool fuse = c->prec == ALEPPO_BF16 && use_patch_kernels() && c->tune.fused_act &&
+                    !(kind == ALEPPO_FRAMES_RAW_PAIR && location != ALEPPO_HOST_MAPPED && c->tune.fused_act < 2);
+  if (fuse) {
+    // ONE launch forms slot t+1's stack from the new frames AND runs conv1 -> conv2 -> conv3 on it, then the split-K fc:
+    // when the next aleppo_act (or aleppo_finish_rollout's bootstrap) arrives only the head + sampling kernel is left.
+    // A slot's critical path is 3 dependent launches instead of 4 and the stack skips one HBM round trip.
+    const SampleMap map = slot_map(c, c->t + 1);
+    prof_begin(c, ALEPPO_K_ACT_FUSED);
+    patch_act_convs(c->stream, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), Pcw(c, P_W2), Pf(c, P_B2), Pcw(c, P_W3),
+                    Pf(c, P_B3), c->a3, E, kind == ALEPPO_FRAMES_RAW_PAIR ? 2 : 1, df, c->lut, &sb, -(long)FRAME_PIX);
+    prof_end(c, ALEPPO_K_ACT_FUSED);
+    prof_begin(c, ALEPPO_K_FC_FWD);
+    fc_fwd_splitk(c->stream, c->prec, c->a3, Pcw(c, P_WFC), c->hpart, E, c->H);
+    prof_end(c, ALEPPO_K_FC_FWD);
+    c->pre_acted = c->t + 1;
+  } else {
+    prof_begin(c, ALEPPO_K_INGEST);
+    launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, nullptr, &sb, c->obs, E, c->T + 1, c->t,
+                  c->t + 1);
+    prof_end(c, ALEPPO_K_INGEST);
+    c->pre_acted = -1;
+  }
   HIPCHK(c, hipGetLastError());
   if (location == ALEPPO_HOST)
     HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
@@ -781,6 +808,7 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->t = 0;
+  c->pre_acted = -1;
   c->need_carry = true;
   c->batch_n = c->N;
   if (*c->h_err)
@@ -823,6 +851,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   const long N = c->batch_n;
   if (N <= 0)
     return set_err(c, ALEPPO_ERR_RUNTIME, "no batch: call aleppo_finish_rollout or aleppo_set_batch first");
+  c->pre_acted = -1; // the update's activations overwrite the acting scratch, and the weights change
   if (N % M != 0)
     return set_err(c, ALEPPO_ERR_RUNTIME, "Batch size must be divisible by num_mini_batches"); // train.h:140-143
   const long B = N / M;
@@ -1071,6 +1100,7 @@ extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, cons
     a32[i] = (int)actions[i];
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->pre_acted = -1;
   int rc = stage_observations(c, observations, n);
   if (rc)
     return rc;
@@ -1108,6 +1138,7 @@ extern "C" int aleppo_forward(aleppo_ctx *c, const uint8_t *observations, int64_
   if (n <= 0 || n > c->maxB)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "forward: n exceeds capacity");
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->pre_acted = -1; // a3 / h are shared scratch
   int rc = stage_observations(c, observations, n);
   if (rc)
     return rc;
@@ -1268,7 +1299,7 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
   else if (option == ALEPPO_OPT_FC_PIPE_WGRAD)
     c->tune.fc_pipe_wgrad = value != 0;
   else if (option == ALEPPO_OPT_FUSED_ACT)
-    c->tune.fused_act = value != 0;
+    c->tune.fused_act = value; // 0: never, 1: where it is faster (default), 2: always
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
   else if (option == ALEPPO_OPT_SERIAL_UPDATE)

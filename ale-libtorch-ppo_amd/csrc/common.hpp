@@ -61,7 +61,7 @@ struct Tuning {
   bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
   bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
   bool fc_pipe_wgrad = false; // opt-in pipelined fc wgrad
-  bool fused_act = true;      // one persistent acting launch per slot (false: ingest / convs / fc / head launches)
+  int fused_act = 1;          // frame ingest fused in front of the acting convolutions: 0 never, 1 where faster, 2 always
 };
 const Tuning &tuning();
 void set_tuning(const Tuning *t); // nullptr -> process defaults
@@ -107,6 +107,7 @@ struct Ctx {
   uint8_t *h_frames = nullptr;
   float *h_noise = nullptr;
   int *h_err = nullptr;
+  int pre_acted = -1;     // slot whose conv stack + split-K fc already ran (fused into aleppo_step); -1: none
   int t = 0;              // next slot to fill
   bool need_carry = false; // copy slot T -> slot 0 before the next rollout's first act
   uint64_t rng_counter = 0;
@@ -252,8 +253,12 @@ void patch_conv2_fwd(hipStream_t s, const void *a1, const void *W2, const float 
 void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float *b3, void *a3, long ns);
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns);
 void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, void *dz1, long ns);
-void patch_act_convs(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
-                     const float *b2, const void *W3, const float *b3, void *a3, long ns);
+// conv1 -> conv2 -> conv3 of the acting batch in one launch; ingest_mode 1 / 2 first forms every environment's stack from
+// a new 84x84 frame / raw frame pair (fused frame ingest: see ActIngestParams in conv_patch.hpp)
+void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
+                     const float *b2, const void *W3, const float *b3, void *a3, long ns, int ingest_mode = 0,
+                     const uint8_t *frames = nullptr, const uint8_t *lut = nullptr, const StartBits *sbits = nullptr,
+                     long src_delta = 0);
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns);
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns);

@@ -17,6 +17,7 @@
 //        both operands are k(=pixel)-outer in LDS and read with ds_read_b64_tr_b16.
 #pragma once
 #include "gemm.hpp"
+#include <type_traits>
 
 namespace aleppo {
 
@@ -444,6 +445,19 @@ struct ActConvParams {
   bf16 *a3;
   long ns;
 };
+// Frame ingest fused in front of the acting convolutions (MODE 1 / 2 of act_conv_kernel): the workgroup of environment
+// n first forms the stack it is about to act on - new frame (MODE 1: given 84x84 bytes; MODE 2: palette LUT + 84x84
+// area resize + 2-frame max of a raw 210x160 pair, the arithmetic of ingest_kernel<true>) shifted into / broadcast
+// over the previous slot's packed stack (rollout.cc:184-196) - writes it to its rollout slot (Buffer::add's
+// observation copy, buffer.cc:47) and keeps it in registers for the widening step: the stack never makes the
+// HBM round trip between an ingest launch and a convolution launch, and the slot's critical path loses a launch.
+struct ActIngestParams {
+  const uint8_t *frames; // MODE 1: [ns][84*84]; MODE 2: [ns][2][210][160]; device or mapped host memory
+  const uint8_t *lut;    // MODE 2: 256-entry palette -> gray table
+  uint32_t *obs_rw;      // the observation slots (same array as ActConvParams::obs)
+  long src_delta;        // previous slot - acted slot, in u32 pixels (the stack to shift)
+  StartBits sbits;       // episode-start flags (bit e of word e / 32)
+};
 
 // Acting phases use ONE 16-channel atom per wave (8 waves = MA channel atoms x 8/MA pixel lanes): the weights
 // of all three layers then fit in registers together (8 + 16 + 18 fragments = 168 VGPRs) and are loaded once,
@@ -514,7 +528,8 @@ constexpr size_t ACT_SMEM = 160 * 1024; // the rest of the LDS stages the layer 
 // at kernel start) and hands it to the waves through LDS regions that are free at that point: conv1's weights in the
 // tail of the LDS, conv2's in the tail + the stack region (dead after conv1), conv3's over stack + a1 (dead after
 // conv2).  Rows are padded by 16 B in LDS (conflict-free fragment reads).
-__global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
+template <int MODE> // 0: act on the stored stack; 1: ingest a given 84x84 frame first; 2: ingest a raw frame pair first
+__global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P, ActIngestParams G) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16 *sx = reinterpret_cast<bf16 *>(smem), *s1 = sx + ACT_X_ELEMS, *s2 = s1 + ACT_A1_ELEMS;
   uint8_t *tail = smem + ACT_ACT_BYTES; // 60 KB
@@ -538,6 +553,97 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       R[i] = src[min(tid + 512 * i, 1763)];
+  };
+  // ---- fused ingest (MODE != 0).  Everything passes through LDS that is dead at this point: the raw frame pair
+  // (67.2 KB, MODE 2) over the stack + a1 regions, the new frame's bytes and the palette table in the a2 region.
+  // MODE 2 stages the pair with whole coalesced 16-byte loads (9 per thread, all in flight together - also the right
+  // shape for frames that sit in mapped host memory) and gathers the 2-3 x 3 source pixels of an output pixel from LDS.
+  uint8_t *sraw = smem;                                 // [2][210][160] raw pair (MODE 2)
+  uint8_t *sfr = reinterpret_cast<uint8_t *>(s2);       // [7056] new-frame bytes
+  uint8_t *slut = sfr + 7168;                           // [256]
+  static_assert(2 * RAW_H * RAW_W <= (ACT_X_ELEMS + ACT_A1_ELEMS) * 2 && 7168 + 256 <= ACT_A2_ELEMS * 2, "ingest LDS map");
+  auto ingest = [&](long n) {
+    const long nn = n + P.map.n0;
+    const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base; // acted slot, u32 pixels
+    if constexpr (MODE == 1) {
+      const u32x4 f = reinterpret_cast<const u32x4 *>(G.frames + n * (long)FRAME_PIX)[min(tid, 440)];
+      if (tid < 441)
+        reinterpret_cast<u32x4 *>(sfr)[tid] = f;
+    } else {
+      // The palette table is applied ONCE per raw byte while the pair is staged (67 K lookups instead of the 106 K an
+      // output-pixel-wise lookup needs: source pixels are shared by neighbouring windows); an output pixel then reads
+      // two aligned dwords per source row (ds_read2_b32), shifts its 2-3 bytes down and adds them with one v_sad_u8.
+      constexpr int NRV = 2 * RAW_H * RAW_W / 16, NRL = (NRV + 511) / 512; // 4200 vectors, 9 per thread
+      const u32x4 *raw = reinterpret_cast<const u32x4 *>(G.frames + n * (long)(2 * RAW_H * RAW_W));
+      u32x4 Q[NRL];
+#pragma unroll
+      for (int i = 0; i < NRL; ++i)
+        Q[i] = raw[min(tid + 512 * i, NRV - 1)];
+      if (tid < 256)
+        slut[tid] = G.lut[tid];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NRL; ++i) {
+        u32x4 o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const uint32_t w = Q[i][d];
+          o[d] = (uint32_t)slut[w & 255u] | ((uint32_t)slut[(w >> 8) & 255u] << 8) |
+                 ((uint32_t)slut[(w >> 16) & 255u] << 16) | ((uint32_t)slut[w >> 24] << 24);
+        }
+        if (tid + 512 * i < NRV)
+          reinterpret_cast<u32x4 *>(sraw)[tid + 512 * i] = o;
+      }
+      __syncthreads();
+      const uint32_t *sraw32 = reinterpret_cast<const uint32_t *>(sraw);
+      for (int pix = tid; pix < FRAME_PIX; pix += 512) {
+        const int i = pix / 84, j = pix - i * 84;
+        const int y0 = (i * RAW_H) / 84, x0 = (j * RAW_W) / 84, x1 = ((j + 1) * RAW_W + 83) / 84; // 3 rows, 2-3 cols
+        const bool wide = (x1 - x0) == 3;
+        const uint32_t keep = wide ? 0x00FFFFFFu : 0x0000FFFFu;
+        int best = 0;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int a = f * (RAW_H * RAW_W) + y0 * RAW_W + x0; // byte offset of the window's first pixel
+          const int sh = (a & 3) * 8;
+          uint32_t sum = 0;
+#pragma unroll
+          for (int y = 0; y < 3; ++y) {
+            const int ai = (a + y * RAW_W) >> 2; // (RAW_W % 4 == 0: the same byte phase in every row)
+            const uint64_t two = (uint64_t)sraw32[ai] | ((uint64_t)sraw32[ai + 1] << 32);
+            sum = __builtin_amdgcn_sad_u8((uint32_t)(two >> sh) & keep, 0u, sum);
+          }
+          best = max(best, (int)rintf((float)sum / (wide ? 9.0f : 6.0f))); // area mean in f32, round-half-even
+        }
+        sfr[pix] = (uint8_t)min(best, 255);
+      }
+    }
+    { // the previous slot's stack: requested now, needed after the barrier
+      const u32x4 *src = reinterpret_cast<const u32x4 *>(G.obs_rw + off + G.src_delta);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        R[i] = src[min(tid + 512 * i, 1763)];
+    }
+    __syncthreads();
+    const bool st = ((G.sbits.w[n >> 5] >> (n & 31)) & 1u) != 0;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(G.obs_rw + off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + 512 * i;
+      if (v < 1764) {
+        const uint32_t fb = reinterpret_cast<const uint32_t *>(sfr)[v]; // the new frame's 4 pixels of this vector
+        u32x4 nvw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t b = (fb >> (8 * j)) & 255u;
+          nvw[j] = st ? b * 0x01010101u : ((R[i][j] << 8) | b); // rollout.cc:184-196, byte 0 = newest frame
+        }
+        R[i] = nvw;
+        dst[v] = nvw; // Buffer::add's observation copy: the stack of the acted slot
+      }
+    }
+    if constexpr (MODE == 2)
+      __syncthreads(); // the widening step overwrites the staged raw pair: every wave must be done gathering from it
   };
   auto widen = [&]() {
     auto pk = [](uint32_t lo, uint32_t hi) { return pack_u8_pair_bf16(lo, hi); };
@@ -577,20 +683,31 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   if (n >= P.ns)
     return;
   // ---- first sample: observation + ONE copy of every layer's weights per workgroup, all requested up front
-  load_obs(n);
+  if constexpr (MODE == 0)
+    load_obs(n);
   u32x4 S1[2], S2[8], S3[9];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
     S1[i] = reinterpret_cast<const u32x4 *>(P.w1)[tid + 512 * i];
+  // (with a fused ingest the conv2 / conv3 weights are requested after it - they would only sit in 68 registers while
+  // the ingest needs them for its own loads - and land during the widening step and conv1)
+  auto load_w23 = [&]() {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    S2[i] = reinterpret_cast<const u32x4 *>(P.w2)[tid + 512 * i];
+    for (int i = 0; i < 8; ++i)
+      S2[i] = reinterpret_cast<const u32x4 *>(P.w2)[tid + 512 * i];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
-    S3[i] = reinterpret_cast<const u32x4 *>(P.w3)[tid + 512 * i];
+    for (int i = 0; i < 9; ++i)
+      S3[i] = reinterpret_cast<const u32x4 *>(P.w3)[tid + 512 * i];
+  };
+  if constexpr (MODE == 0)
+    load_w23();
   W1.load_bias(P.b1, wave, lane);
   W2.load_bias(P.b2, wave, lane);
   W3.load_bias(P.b3, wave, lane);
+  if constexpr (MODE != 0) {
+    ingest(n);
+    load_w23();
+  }
   widen();
 #pragma unroll
   for (int i = 0; i < 2; ++i) // conv1 weights [32][256] -> tail
@@ -621,7 +738,10 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P) {
   __syncthreads();
   // ---- further samples of this workgroup (more environments than CUs): the weights stay in registers
   for (n += gridDim.x; n < P.ns; n += gridDim.x) {
-    load_obs(n);
+    if constexpr (MODE == 0)
+      load_obs(n);
+    else
+      ingest(n);
     widen();
     __syncthreads();
     conv1();

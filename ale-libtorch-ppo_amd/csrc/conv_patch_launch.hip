@@ -99,16 +99,32 @@ void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const vo
   launch_patch<LConv2DgradW4, 4, 2>(s, P); // 2 per CU: the preloaded gates take the kernel to 196 VGPRs
 }
 
-void patch_act_convs(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
-                     const float *b2, const void *W3, const float *b3, void *a3, long ns) {
+void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
+                     const float *b2, const void *W3, const float *b3, void *a3, long ns, int ingest_mode,
+                     const uint8_t *frames, const uint8_t *lut, const StartBits *sbits, long src_delta) {
   static bool once = false;
   if (!once) {
-    allow_smem(act_conv_kernel, ACT_SMEM);
+    allow_smem(act_conv_kernel<0>, ACT_SMEM);
+    allow_smem(act_conv_kernel<1>, ACT_SMEM);
+    allow_smem(act_conv_kernel<2>, ACT_SMEM);
     once = true;
   }
   ActConvParams P{obs, map, static_cast<const bf16 *>(W1), static_cast<const bf16 *>(W2), static_cast<const bf16 *>(W3),
                   b1,  b2,  b3, static_cast<bf16 *>(a3), ns};
-  hipLaunchKernelGGL(act_conv_kernel, dim3((unsigned)std::min<long>(ns, num_cus())), dim3(512), ACT_SMEM, s, P);
+  ActIngestParams G{};
+  G.frames = frames;
+  G.lut = lut;
+  G.obs_rw = obs;
+  G.src_delta = src_delta;
+  if (sbits)
+    G.sbits = *sbits;
+  const dim3 g((unsigned)std::min<long>(ns, num_cus())), b(512);
+  if (ingest_mode == 1)
+    hipLaunchKernelGGL(act_conv_kernel<1>, g, b, ACT_SMEM, s, P, G);
+  else if (ingest_mode == 2)
+    hipLaunchKernelGGL(act_conv_kernel<2>, g, b, ACT_SMEM, s, P, G);
+  else
+    hipLaunchKernelGGL(act_conv_kernel<0>, g, b, ACT_SMEM, s, P, G);
 }
 
 template <class L> static int launch_wgrad(hipStream_t s, const WgradParams &P) {

@@ -301,9 +301,11 @@ def run(args):
                                          "kernels co-scheduled on the second stream")
         roofline["update_other_kernel_ms"] = {k: round(v[0], 4) for k, v in trn.items() if v[1] and k not in KFLOP}
         roofline["acting_kernel_ms_per_step"] = {k: round(v[0], 4) for k, v in act.items() if v[1]}
-        ing_ms = act["ingest"][0]
+        # frame ingest: its own kernel, or fused in front of the acting convolutions (then the launch also does conv1-3)
+        ing_ms = act["ingest"][0] or act["act_fused"][0] or float("nan")
         roofline["hbm_kernels"] = dict(
             ingest_GBps=round(74256 * E / (ing_ms * 1e-3) / 1e9, 1), ingest_frac=round(74256 * E / (ing_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            ingest_kernel="ingest_kernel" if act["ingest"][1] else "act_conv_kernel<2> (ingest + conv1-3 in one launch)",
             gae_GBps=round(23 * E * T / (act["gae"][0] * 1e-3) / 1e9, 2),
             adam_GBps=round(28 * eng.param_count / (trn["adam"][0] * 1e-3) / 1e9, 1),
             head_GBps=round((97 + 2 * 512 * 4) * B / (trn["head"][0] * 1e-3) / 1e9, 1))

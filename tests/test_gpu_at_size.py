@@ -266,6 +266,38 @@ def test_replay_from_mapped_host_memory_equals_device_frames(pkg):
     dev.free()
 
 
+@pytest.mark.parametrize("kind", ["84", "raw"])
+def test_fused_ingest_acting_launch_equals_separate_launches(pkg, kind):
+    """bf16 acting: aleppo_step's ONE launch (frame ingest + conv1-3, act_conv_kernel<1 / 2>) against the separate
+    ingest_kernel + act_conv_kernel<0> launches (ALEPPO_OPT_FUSED_ACT = 0): identical bytes in every plane.  E = 300 >
+    256 CUs: workgroups loop over environments (weights stay in registers, LDS regions are recycled)."""
+    E, T, A, H = 300, 4, 6, 512
+    per_env = 84 * 84 if kind == "84" else 2 * 210 * 160
+    frames = hf.hf_bytes(2011, (T, E, per_env))
+    dev = DeviceBytes(frames)
+    te, tr, st = _flags(2012, T, E, 0.2, 0.1)
+    rew = hf.hf_range(2013, (T, E), -2, 2)
+    noise = np.random.default_rng(2015).exponential(size=(T, E, A)).astype(np.float32)
+    lut = ((np.arange(256) * 3 + 7) % 256).astype(np.uint8)
+    got = []
+    for fused in (0, 2):  # 2: fused for every frame kind and location
+        eng = pkg.Engine(E, T, A, H, precision=pkg.BF16, seed=4)
+        eng.set_option(pkg.OPT_FUSED_ACT, fused)
+        eng.load_params(hf.fill_params(2010, H, A))
+        eng.set_gray_lut(lut)
+        for ro in range(2):
+            eng.replay_rollout(dev.addr, pkg.FRAMES_84 if kind == "84" else pkg.FRAMES_RAW_PAIR, E * per_env, rew, te,
+                               tr, st, noise=noise)
+            eng.finish_rollout(noise[0])
+        got.append({k: eng.read_batch(k) for k in ("observations", "current_obs", "actions", "logits", "values",
+                                                   "next_values", "advantages", "returns")})
+        eng.close()
+    dev.free()
+    for k in got[0]:
+        np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=k)
+    assert got[0]["observations"].any()
+
+
 # ------------------------------------------------------------------ advantage normalisation (extension; unpinned)
 @pytest.mark.parametrize("E,T", [(6, 9), (128, 32)])
 def test_advantage_norm_extension_vs_oracle(pkg, E, T):
