@@ -53,7 +53,7 @@ EXPORTS = [
     "aleppo_comm_init", "aleppo_gae", "aleppo_vision_resize_area", "aleppo_vision_rgb_to_gray", "aleppo_preprocess",
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
     "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option", "aleppo_export_optimizer",
-    "aleppo_import_optimizer", "aleppo_replay_rollout",
+    "aleppo_import_optimizer", "aleppo_replay_rollout", "aleppo_get_option",
 ]
 
 
@@ -424,6 +424,11 @@ class Engine:
     def set_option(self, option, value):
         """aleppo_set_option: per-context A/B switches (OPT_*)"""
         self._c(lib().aleppo_set_option(self._ctx, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int64()
+        self._c(lib().aleppo_get_option(self._ctx, int(option), C.byref(v)))
+        return v.value
 
     def set_generic_conv(self, on):
         """A/B switch: run bf16 convolutions on the generic gather-GEMM kernels (this context only)."""

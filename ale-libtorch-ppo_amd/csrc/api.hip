@@ -414,6 +414,10 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
   set_tuning(nullptr);
   (void)hipSetDevice(c->cfg.device_ordinal);
   hipDeviceSynchronize();
+  if (c->graph_exec)
+    hipGraphExecDestroy(c->graph_exec);
+  if (c->graph)
+    hipGraphDestroy(c->graph);
   if (c->nccl_comm)
     ncclCommDestroy(static_cast<ncclComm_t>(c->nccl_comm));
   void *dev[] = {c->obs,   c->step_rec, c->values_tm, c->logits_tm, c->actions_tm, c->lut,     c->d_start,
@@ -421,13 +425,15 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
                  c->mask_n, c->mask_counts, c->P,    c->G,         c->Gs,         c->M1,      c->M2,
                  c->W2d,   c->W3d,      c->WfcT,      c->a1,        c->a2,         c->a3,      c->dz1,
                  c->dz2,   c->dz3,      c->h,         c->hpart,     c->dh,        c->logits_b,   c->values_b, c->slab,
-                 c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats, c->stage_u8, c->stage_obs};
+                 c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats, c->stage_u8, c->stage_obs,
+                 c->adam_sched};
   for (void *p : dev)
     if (p)
       hipFree(p);
   if (c->Pc && c->Pc != c->P)
     hipFree(c->Pc);
-  void *host[] = {c->h_actions, c->h_step, c->h_rec, c->h_frames, c->h_noise, c->h_err, c->h_metric_red};
+  void *host[] = {c->h_actions, c->h_step, c->h_rec, c->h_frames, c->h_noise, c->h_err, c->h_metric_red,
+                  c->h_adam_sched};
   for (void *p : host)
     if (p)
       hipHostFree(p);
@@ -835,10 +841,16 @@ static int ensure_metric_storage(aleppo_ctx *c, int epochs, int M, long B) {
       hipFree(c->grad_norms);
     if (c->h_metric_red)
       hipHostFree(c->h_metric_red);
-    c->metric_red = c->grad_norms = c->h_metric_red = nullptr;
+    if (c->adam_sched)
+      hipFree(c->adam_sched);
+    if (c->h_adam_sched)
+      hipHostFree(c->h_adam_sched);
+    c->metric_red = c->grad_norms = c->h_metric_red = c->adam_sched = c->h_adam_sched = nullptr;
     HIPCHK(c, dalloc(&c->metric_red, nm * 8 * 4));
     HIPCHK(c, dalloc(&c->grad_norms, nm * 4));
+    HIPCHK(c, dalloc(&c->adam_sched, nm * 2 * 4));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_metric_red), nm * 9 * 4, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_adam_sched), nm * 2 * 4, hipHostMallocDefault));
     c->metric_red_cap = nm;
   }
   return ALEPPO_OK;
@@ -871,9 +883,15 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   hipStream_t s = c->stream;
   const Hyper hp{c->cfg.clip_param, c->cfg.value_loss_coef, c->cfg.entropy_coef, c->cfg.max_gradient_norm};
 
-  launch_mask_count(s, c->mask_n, c->mask_counts, B, M);
-  if (dp) // N_m of the masked mean is the GLOBAL count (SURVEY 8e)
-    NCCLCHK(c, ncclAllReduce(c->mask_counts, c->mask_counts, M, ncclFloat, ncclSum, comm, s));
+  // Adam's per-step scalars for the whole call, uploaded once: step size lr / (1 - beta1^t) and sqrt(1 - beta2^t) are
+  // DEVICE values the Adam kernel reads (kernel arguments would be baked into a captured graph)
+  const int nm = epochs * M;
+  for (int i = 0; i < nm; ++i) {
+    const double b1 = c->cfg.adam_beta1, b2 = c->cfg.adam_beta2, t = (double)(c->adam_step + i + 1);
+    c->h_adam_sched[2 * i] = (float)(lr / (1.0 - std::pow(b1, t)));
+    c->h_adam_sched[2 * i + 1] = (float)std::sqrt(1.0 - std::pow(b2, t));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->adam_sched, c->h_adam_sched, (size_t)nm * 8, hipMemcpyHostToDevice, s));
 
   float *sW1 = c->slab + c->slab_off[0], *sB1 = c->slab + c->slab_off[1], *sW2 = c->slab + c->slab_off[2],
         *sB2 = c->slab + c->slab_off[3], *sW3 = c->slab + c->slab_off[4], *sB3 = c->slab + c->slab_off[5],
@@ -899,6 +917,12 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     const hipError_t e = hipEventRecord(ev, s);
     return e != hipSuccess ? e : hipStreamWaitEvent(sw, ev, 0);
   };
+  // Everything the update enqueues - mask counts, epochs x minibatches of forward / loss / backward / [all-reduce] /
+  // clip / Adam, the metric reduction - as one function: run eagerly, or recorded once into a hipGraph and replayed.
+  auto enqueue_update = [&]() -> int {
+  launch_mask_count(s, c->mask_n, c->mask_counts, B, M);
+  if (dp) // N_m of the masked mean is the GLOBAL count (SURVEY 8e)
+    NCCLCHK(c, ncclAllReduce(c->mask_counts, c->mask_counts, M, ncclFloat, ncclSum, comm, s));
   bool pack_pending = false;
   for (int ep = 0; ep < epochs; ++ep)
     for (int mb = 0; mb < M; ++mb) { // contiguous env-major slices; randperm unused (Q1)
@@ -1016,11 +1040,8 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_begin(c, ALEPPO_K_ADAM);
       // (pads between tensors are zero: only [0, off[P_W1]) and the two conv1 tensors contribute)
       const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail);
-      c->adam_step += 1;
-      const double b1 = c->cfg.adam_beta1, b2 = c->cfg.adam_beta2;
-      const double bc1 = 1.0 - std::pow(b1, (double)c->adam_step), bc2 = 1.0 - std::pow(b2, (double)c->adam_step);
       launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, prec, (long)L.total(),
-                  c->sumsq_part, nblk_norm, hp.max_norm, (float)(lr / bc1), (float)std::sqrt(bc2), (float)b1, (float)b2,
+                  c->sumsq_part, nblk_norm, hp.max_norm, c->adam_sched + 2 * mi, c->cfg.adam_beta1, c->cfg.adam_beta2,
                   c->cfg.adam_eps, c->grad_norms + mi);
       prof_end(c, ALEPPO_K_ADAM);
       // The dgrad weight layouts (W2d, W3d, WfcT) are first needed by the NEXT minibatch's fc dgrad: repack them
@@ -1033,11 +1054,56 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     }
   if (pack_pending)
     HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
-  HIPCHK(c, hipGetLastError());
-  const int nm = epochs * M;
   launch_metrics_reduce(s, c->metric_ps, fs, c->mask_n, B, M, epochs, c->metric_red);
   if (dp)
     NCCLCHK(c, ncclAllReduce(c->metric_red, c->metric_red, (size_t)nm * 8, ncclFloat, ncclSum, comm, s));
+  return ALEPPO_OK;
+  }; // enqueue_update
+
+  // ALEPPO_OPT_UPDATE_GRAPH (capture_train_cuda_graph, train.h:163-195): the first call of a shape runs eagerly (it also
+  // performs the kernels' one-time attribute set-up), the second records the same enqueue into a graph, later calls
+  // replay it.  Not with data parallelism (the collectives stay eager) and not while per-kernel profiling brackets launches.
+  Ctx::GraphKey key;
+  key.epochs = epochs;
+  key.M = M;
+  key.two = two ? 1 : 0;
+  key.N = N;
+  key.metric_ps = c->metric_ps;
+  key.metric_red = c->metric_red;
+  const bool want_graph = c->update_graph && !dp && !c->prof_on;
+  if (want_graph && c->graph_exec && c->graph_key == key) {
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, s));
+    c->graph_replays++;
+  } else if (want_graph && c->warm_key == key) {
+    if (c->graph_exec)
+      HIPCHK(c, hipGraphExecDestroy(c->graph_exec));
+    if (c->graph)
+      HIPCHK(c, hipGraphDestroy(c->graph));
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_update();
+    hipGraph_t g = nullptr;
+    const hipError_t ee = hipStreamEndCapture(s, &g); // (also ends a capture that failed half way)
+    if (rc) {
+      if (g)
+        hipGraphDestroy(g);
+      return rc;
+    }
+    HIPCHK(c, ee);
+    c->graph = g;
+    HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+    c->graph_key = key;
+    HIPCHK(c, hipGraphLaunch(c->graph_exec, s));
+    c->graph_replays++;
+  } else {
+    rc = enqueue_update();
+    if (rc)
+      return rc;
+    c->warm_key = key;
+  }
+  c->adam_step += nm;
+  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_metric_red, c->metric_red, (size_t)nm * 8 * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipMemcpyAsync(c->h_metric_red + (size_t)nm * 8, c->grad_norms, (size_t)nm * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1306,8 +1372,27 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->serial_update = value != 0;
   else if (option == ALEPPO_OPT_FORCE_COMM)
     c->force_comm = value != 0;
+  else if (option == ALEPPO_OPT_UPDATE_GRAPH)
+    c->update_graph = value != 0;
   else
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
+  CHECK_CTX(c);
+  if (!value)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null value");
+  switch (option) {
+  case ALEPPO_OPT_GENERIC_CONV: *value = c->tune.patch_conv ? 0 : 1; break;
+  case ALEPPO_OPT_DEBUG_NO_PUBLISH: *value = c->dbg_no_publish; break;
+  case ALEPPO_OPT_FORCE_COMM: *value = c->force_comm; break;
+  case ALEPPO_OPT_SERIAL_UPDATE: *value = c->serial_update; break;
+  case ALEPPO_OPT_FC_PIPE: *value = c->tune.fc_pipe; break;
+  case ALEPPO_OPT_FC_PIPE_WGRAD: *value = c->tune.fc_pipe_wgrad; break;
+  case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
+  case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
+  default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
+  }
   return ALEPPO_OK;
 }
 extern "C" int aleppo_profile_enable(aleppo_ctx *c, int on) {

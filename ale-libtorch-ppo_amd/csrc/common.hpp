@@ -140,6 +140,22 @@ struct Ctx {
   size_t metric_red_cap = 0;
   float *metric_red = nullptr, *h_metric_red = nullptr;
   float *grad_norms = nullptr; // [mi]
+  float *adam_sched = nullptr, *h_adam_sched = nullptr; // [mi][2] step scalars of one aleppo_train call (device / pinned)
+  // ---- captured update (ALEPPO_OPT_UPDATE_GRAPH): the epochs x minibatches loop as one hipGraph, re-captured when
+  // the shape (or a baked pointer) changes; the first call of a shape runs eagerly (one-time kernel attribute set-up)
+  bool update_graph = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    int epochs = 0, M = 0, two = 0;
+    long N = 0;
+    const void *metric_ps = nullptr, *metric_red = nullptr;
+    bool operator==(const GraphKey &o) const {
+      return epochs == o.epochs && M == o.M && two == o.two && N == o.N && metric_ps == o.metric_ps &&
+             metric_red == o.metric_red;
+    }
+  } graph_key, warm_key;
+  long graph_replays = 0;
   int last_epochs = 0, last_M = 0;
   long last_B = 0;
   // ---- profiling ----
@@ -203,7 +219,8 @@ void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *
 // returns the number of partials written (<= 1024)
 int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2]);
 void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
-                 int prec, long n, const float *partials, int nblk, float max_norm, float step_size, float bc2_sqrt,
+                 int prec, long n, const float *partials, int nblk, float max_norm,
+                 const float *sched, // device: { lr / (1 - beta1^t), sqrt(1 - beta2^t) } of this step
                  float beta1, float beta2, float eps, float *grad_norm_out);
 void launch_pack_dgrad(hipStream_t s, const float *P, const ParamLayout &L, void *W2d, void *W3d, void *WfcT,
                        int prec);

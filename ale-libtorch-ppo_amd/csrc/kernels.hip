@@ -1001,7 +1001,7 @@ int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk
 template <class T>
 __global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__restrict__ G, float *Gs, float *M1, float *M2,
                                                     T *Pc, long n, const float *__restrict__ partials, int nblk,
-                                                    float max_norm, float step_size, float bc2_sqrt, float beta1,
+                                                    float max_norm, const float *__restrict__ sched, float beta1,
                                                     float beta2, float eps, float *grad_norm_out) {
   __shared__ float s4[4];
   float s = 0.f;
@@ -1013,6 +1013,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__rest
   coef = fminf(coef, 1.0f);               // train.cc:40-41
   if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm_out)
     *grad_norm_out = norm;                // pre-clip norm is what the reference reports (Q9)
+  // lr / (1 - beta1^t) and sqrt(1 - beta2^t) of THIS optimizer step: device scalars (a captured hipGraph of the update
+  // follows the annealed rate and the step count; the reference's captured graph bakes both, train.h:163-195)
+  const float step_size = sched[0], bc2_sqrt = sched[1];
   const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float g = G[i] * coef;          // train.cc:42-44 (always applied)
@@ -1030,16 +1033,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__rest
   }
 }
 void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
-                 int prec, long n, const float *partials, int nblk, float max_norm, float step_size, float bc2_sqrt,
+                 int prec, long n, const float *partials, int nblk, float max_norm, const float *sched,
                  float beta1, float beta2, float eps, float *grad_norm_out) {
   const int nb = (int)std::min<long>((n + 255) / 256, 2048);
   if (prec == ALEPPO_BF16)
     hipLaunchKernelGGL(adam_kernel<bf16>, dim3(nb), dim3(256), 0, s, P, G_in, G_out_scaled, M1, M2,
-                       static_cast<bf16 *>(Pc), n, partials, nblk, max_norm, step_size, bc2_sqrt, beta1, beta2, eps,
+                       static_cast<bf16 *>(Pc), n, partials, nblk, max_norm, sched, beta1, beta2, eps,
                        grad_norm_out);
   else
     hipLaunchKernelGGL(adam_kernel<float>, dim3(nb), dim3(256), 0, s, P, G_in, G_out_scaled, M1, M2,
-                       static_cast<float *>(nullptr), n, partials, nblk, max_norm, step_size, bc2_sqrt, beta1, beta2,
+                       static_cast<float *>(nullptr), n, partials, nblk, max_norm, sched, beta1, beta2,
                        eps, grad_norm_out);
 }
 

@@ -123,6 +123,8 @@ def run(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hashfill as hf
     eng.load_params(hf.fill_params(310, H, A))
+    if args.update_graph:
+        eng.set_option(pkg.OPT_UPDATE_GRAPH, 1)
     lut = (np.arange(256) // 2 * 2).astype(np.uint8)
     eng.set_gray_lut(lut)
 
@@ -372,7 +374,8 @@ def run(args):
                                    f"{epochs} epochs x {M} minibatches of {E * T // M} (configs[1], v0.yaml update shape)",
                        "envs_per_gpu": E, "horizon": T, "epochs": epochs, "minibatches": M,
                        "parallelism": f"dp{world}", "frames": "raw u8 [E,2,210,160] pairs resident in HBM",
-                       "rollout_planes": "fp16" if args.rollout_fp16 else "fp32"},
+                       "rollout_planes": "fp16" if args.rollout_fp16 else "fp32",
+                       "update_graph": bool(args.update_graph)},
             "roofline": roofline, "cpu_baseline": cpu, "host_frames": host_legs,
             "vs_reference_published_v1_26289": round(value / 26289.0, 2), "v1_shape": v1,
             "last_loss": float(metrics["loss"][-1, -1]), "last_grad_norm": float(metrics["grad_norm"][-1, -1]),
@@ -493,5 +496,7 @@ if __name__ == "__main__":
     ap.add_argument("--no-host-legs", action="store_true", help="skip the frames-in-pinned-host-memory legs")
     ap.add_argument("--rollout-fp16", action="store_true",
                     help="BASELINE configs[4]: half-precision rollout planes (use with --envs 256 --actions 6)")
+    ap.add_argument("--update-graph", type=int, default=0,
+                    help="1: replay the update loop as a captured hipGraph (the reference's `cuda_graph: true`)")
     ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py spawns the ranks")
     run(ap.parse_args())

@@ -289,6 +289,9 @@ typedef enum {
                                       corrections are device scalars, so a replay follows the annealed rate */
 } aleppo_option;
 int aleppo_set_option(aleppo_ctx *ctx, int option, int value);
+/* Current value of an option; for ALEPPO_OPT_UPDATE_GRAPH the number of graph launches so far (0 = every update ran
+ * eagerly), for the others the value last set / the default. */
+int aleppo_get_option(aleppo_ctx *ctx, int option, int64_t *value);
 /* Block until everything enqueued on ctx's streams has finished. */
 int aleppo_synchronize(aleppo_ctx *ctx);
 

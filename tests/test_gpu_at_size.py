@@ -298,6 +298,46 @@ def test_fused_ingest_acting_launch_equals_separate_launches(pkg, kind):
     assert got[0]["observations"].any()
 
 
+# ------------------------------------------------------------------ N3: the update as a captured hipGraph
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_captured_update_graph_is_bit_identical_to_eager(pkg, prec):
+    """ALEPPO_OPT_UPDATE_GRAPH (capture_train_cuda_graph, train.h:163-195): call 1 runs eagerly, call 2 captures the
+    epochs x minibatches loop (two streams, cross-stream events) into a hipGraph, calls 3-4 replay it.  The learning
+    rate is annealed between calls (train.cc:424-428) and Adam's bias corrections advance: both are device scalars, so a
+    replay must follow them (the reference's captured graph bakes them) - every call bit-identical to the eager engine."""
+    E, T, A, H, M, epochs = (128, 32, 4, 512, 2, 2) if prec == "bf16" else (16, 8, 6, 64, 2, 2)
+    N = E * T
+    params = hf.fill_params(2110, H, A)
+    base = hf.hf_bytes(2111, (N // 8, 4, 84, 84))
+    obs = np.concatenate([base ^ np.uint8(17 * k) for k in range(8)])
+    actions = (hf.hf_u32(2112, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(2113, (N, A), -1, 1))
+    adv, ret = hf.hf_range(2114, (N,), -1, 1), hf.hf_range(2115, (N,), -1, 1)
+    masks = (hf.hf_unit(2116, N) >= np.float32(0.05)).astype(np.uint8)
+    outs = []
+    for graph in (0, 1):
+        eng = pkg.Engine(E, T, A, H, precision=pkg.BF16 if prec == "bf16" else pkg.FP32)
+        eng.set_option(pkg.OPT_UPDATE_GRAPH, graph)
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        hist = []
+        for call in range(4):
+            m = eng.train(pkg.learning_rate(2.5e-4, call, 8), epochs, M)
+            hist.append((m["loss"].copy(), m["grad_norm"].copy(), eng.export_params()))
+        sd = eng.state_dict()
+        outs.append((hist, sd["exp_avg"].copy(), sd["exp_avg_sq"].copy(), int(sd["step"])))
+        assert eng.get_option(pkg.OPT_UPDATE_GRAPH) == (3 if graph else 0)  # calls 2-4 went through the graph
+        eng.close()
+    eager, graph = outs
+    assert eager[3] == graph[3] == 4 * epochs * M
+    for call in range(4):
+        for a, b in zip(eager[0][call], graph[0][call]):
+            np.testing.assert_array_equal(a, b, err_msg=f"call {call}")
+    np.testing.assert_array_equal(eager[1], graph[1])
+    np.testing.assert_array_equal(eager[2], graph[2])
+    assert np.abs(eager[0][3][2] - eager[0][2][2]).max() > 0  # the replays kept learning
+
+
 # ------------------------------------------------------------------ advantage normalisation (extension; unpinned)
 @pytest.mark.parametrize("E,T", [(6, 9), (128, 32)])
 def test_advantage_norm_extension_vs_oracle(pkg, E, T):
