@@ -54,6 +54,7 @@ EXPORTS = [
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
     "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option", "aleppo_export_optimizer",
     "aleppo_import_optimizer", "aleppo_replay_rollout", "aleppo_get_option",
+    "aleppo_host_alloc", "aleppo_host_free",
 ]
 
 
@@ -350,6 +351,15 @@ class Engine:
         self._c(lib().aleppo_replay_rollout(self._ctx, C.c_void_p(frames_addr), int(kind), int(location),
                                             C.c_size_t(slot_stride_bytes), _ptr(r), _ptr(te), _ptr(tr), _ptr(st),
                                             _ptr(nz)))
+
+    def host_alloc(self, nbytes):
+        """mapped page-locked host memory for frame buffers (pass its address with location=HOST_MAPPED)"""
+        p = C.c_void_p()
+        self._c(lib().aleppo_host_alloc(self._ctx, C.c_size_t(nbytes), C.byref(p)))
+        return p.value
+
+    def host_free(self, addr):
+        self._c(lib().aleppo_host_free(self._ctx, C.c_void_p(addr)))
 
     def set_gray_lut(self, lut):
         self._c(lib().aleppo_set_gray_lut(self._ctx, _ptr(_u8(lut))))

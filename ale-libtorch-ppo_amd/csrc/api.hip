@@ -778,6 +778,23 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
   }
   return ALEPPO_OK;
 }
+extern "C" int aleppo_host_alloc(aleppo_ctx *c, size_t bytes, void **ptr) {
+  CHECK_CTX(c);
+  if (!ptr || bytes == 0)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "host_alloc: bad argument");
+  *ptr = nullptr;
+  HIPCHK(c, hipHostMalloc(ptr, bytes, hipHostMallocMapped));
+  std::memset(*ptr, 0, bytes);
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_host_free(aleppo_ctx *c, void *ptr) {
+  CHECK_CTX(c);
+  if (!ptr)
+    return ALEPPO_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream)); // a kernel may still be reading it
+  HIPCHK(c, hipHostFree(ptr));
+  return ALEPPO_OK;
+}
 extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
   CHECK_CTX(c);
   if (!lut256)

@@ -158,6 +158,13 @@ int aleppo_act(aleppo_ctx *ctx, const float *noise, const int64_t **actions_pinn
  * episode_start: uint8 [E] = is_episode_start_cpu_ at ENTRY of this slot (rollout.cc:190). */
 int aleppo_push_frames(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int location,
                        const uint8_t *episode_start);
+/* Page-locked host memory the GPU can address, for the buffers the emulator worker threads write their frames into
+ * (replaces Rollout::screen_buffers_, src/ai/rollout.cc:325-326): pass it to aleppo_step / aleppo_push_frames with
+ * ALEPPO_HOST_MAPPED and the ingest kernel reads the frames in place - no staging copy on the slot's critical path.
+ * The caller must not rewrite a buffer before the aleppo_act / aleppo_finish_rollout that follows its aleppo_step has
+ * returned (the emulators are stepped after aleppo_act, so the natural loop satisfies this with ONE buffer). */
+int aleppo_host_alloc(aleppo_ctx *ctx, size_t bytes, void **ptr);
+int aleppo_host_free(aleppo_ctx *ctx, void *ptr);
 /* 256-entry palette -> gray LUT used by ALEPPO_FRAMES_RAW_PAIR (default: identity). */
 int aleppo_set_gray_lut(aleppo_ctx *ctx, const uint8_t *lut256);
 

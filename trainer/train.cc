@@ -11,7 +11,15 @@
 //   * warm rollout before the loop, linear lr anneal, "Rollout i of N", scalar logging
 //                                                                            (src/bin/train.cc:391-458,163-210)
 //   * orthogonal init with gains sqrt(2) / 0.01 / 1, zero biases            (src/bin/train.cc:212-253)
-//   * a TensorBoard event file (TFRecord + hand-encoded protobuf; scalars and histograms)
+//   * a TensorBoard event file (TFRecord + hand-encoded protobuf): every scalar and histogram of log_data
+//     (src/bin/train.cc:163-210) and the hparams session record of logger.add_hparams (:72-105, :389)
+//   * the optional 6th argument [profile] (src/bin/train.cc:409-419, 459-462 save a Kineto trace there): a
+//     chrome://tracing / Perfetto JSON of every C-ABI call (host spans) plus the per-kernel-class device times the
+//     library measures with HIP events; the same spans are roctx ranges (rocprofv3 --marker-trace) when libroctx64.so
+//     is loadable
+//   * the emulator threads write their frames into ONE page-locked, GPU-mapped buffer (aleppo_host_alloc) that the
+//     ingest kernel reads in place (ALEPPO_HOST_MAPPED) - no per-slot staging copy (rollout.cc:325-326 memcpy's into
+//     per-env host vectors that update_observations then stacks and uploads)
 // ALE is not available in this build environment (no headers, no ROMs): the emulator behind the
 // VirtualEnvironment-like interface is a deterministic synthetic Atari-shaped game (84x84 gray frames,
 // 5 lives, reward on "brick hits", terminal on life loss like EpisodeLife, truncation at max_steps /
@@ -27,6 +35,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <filesystem>
 #include <fstream>
 #include <functional>
@@ -390,6 +399,49 @@ public:
     e.bytes(5, s.b);
     record(e.b);
   }
+  // logger.add_hparams(get_parameters(config), group_name, start_time) (src/bin/train.cc:72-105, :389): the HParams
+  // plugin's session-start record.  Summary.Value{tag "_hparams_/session_start_info", metadata.plugin_data{plugin_name
+  // "hparams", content = HParamsPluginData{version 0, session_start_info{hparams map<string, google.protobuf.Value>,
+  // group_name, start_time_secs}}}}
+  void add_hparams(const std::vector<std::pair<std::string, double>> &numbers,
+                   const std::vector<std::pair<std::string, bool>> &flags, const std::string &group, double start_secs) {
+    Pb ssi;
+    auto entry = [&](const std::string &k, const Pb &val) {
+      Pb kv; // map entry: key = 1, value = 2
+      kv.bytes(1, k);
+      kv.bytes(2, val.b);
+      ssi.bytes(1, kv.b);
+    };
+    for (auto &n : numbers) {
+      Pb v;
+      v.f64(2, n.second); // google.protobuf.Value.number_value
+      entry(n.first, v);
+    }
+    for (auto &b : flags) {
+      Pb v;
+      v.i64(4, b.second ? 1 : 0); // google.protobuf.Value.bool_value
+      entry(b.first, v);
+    }
+    ssi.bytes(4, group);
+    ssi.f64(5, start_secs);
+    Pb plugin; // HParamsPluginData: version = 1, session_start_info = 3
+    plugin.i64(1, 0);
+    plugin.bytes(3, ssi.b);
+    Pb pd; // SummaryMetadata.PluginData: plugin_name = 1, content = 2
+    pd.bytes(1, "hparams");
+    pd.bytes(2, plugin.b);
+    Pb md; // SummaryMetadata: plugin_data = 1
+    md.bytes(1, pd.b);
+    Pb v; // Summary.Value: tag = 1, metadata = 9
+    v.bytes(1, "_hparams_/session_start_info");
+    v.bytes(9, md.b);
+    Pb s;
+    s.bytes(1, v.b);
+    Pb e;
+    e.f64(1, now());
+    e.bytes(5, s.b);
+    record(e.b);
+  }
   void flush() { f_.flush(); }
 
 private:
@@ -404,6 +456,90 @@ private:
     f_.write(reinterpret_cast<const char *>(&c2), 4);
   }
   std::ofstream f_;
+};
+
+// ------------------------------------------------------------------ [profile] argument: host spans + roctx ranges
+class Profile {
+public:
+  explicit Profile(const std::string &path) : path_(path), t0_(std::chrono::steady_clock::now()) {
+    if (path_.empty())
+      return;
+    if (void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL)) { // optional: markers for rocprofv3 --marker-trace
+      push_ = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+      pop_ = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    }
+  }
+  bool on() const { return !path_.empty(); }
+  struct Span {
+    Profile *p;
+    const char *name;
+    double t0;
+    Span(Profile *p_, const char *n) : p(p_), name(n), t0(0) {
+      if (!p->on())
+        return;
+      t0 = p->now_us();
+      if (p->push_)
+        p->push_(name);
+    }
+    ~Span() {
+      if (!p->on())
+        return;
+      if (p->pop_)
+        p->pop_();
+      p->events_.push_back({name, t0, p->now_us() - t0});
+    }
+  };
+  void device_summary(aleppo_ctx *ctx) { // per-kernel-class device time (HIP events on the kernels' streams)
+    static const char *names[ALEPPO_K_COUNT] = {"ingest", "gae", "head", "adam", "conv1_fwd", "conv2_fwd", "conv3_fwd",
+                                                "fc_fwd", "fc_dgrad", "fc_wgrad", "conv3_dgrad", "conv3_wgrad",
+                                                "conv2_dgrad", "conv2_wgrad", "conv1_wgrad", "reduce", "infer_head",
+                                                "act_fused"};
+    for (int k = 0; k < ALEPPO_K_COUNT; ++k) {
+      double ms = 0;
+      int64_t n = 0;
+      if (aleppo_profile_read(ctx, k, &ms, &n) == ALEPPO_OK && n > 0)
+        device_.push_back({names[k], ms, n});
+    }
+  }
+  void save() {
+    if (!on())
+      return;
+    std::ofstream f(path_);
+    f << "{\"traceEvents\": [\n";
+    bool first = true;
+    for (auto &e : events_) {
+      f << (first ? "" : ",\n") << "{\"name\": \"" << e.name << "\", \"ph\": \"X\", \"pid\": 1, \"tid\": 1, \"ts\": "
+        << e.ts << ", \"dur\": " << e.dur << "}";
+      first = false;
+    }
+    f << "\n],\n\"device_kernel_classes\": [\n";
+    first = true;
+    for (auto &d : device_) {
+      f << (first ? "" : ",\n") << "{\"kernel_class\": \"" << d.name << "\", \"avg_ms\": " << d.ms
+        << ", \"launches\": " << d.n << "}";
+      first = false;
+    }
+    f << "\n]}\n";
+  }
+
+private:
+  friend struct Span;
+  double now_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count(); }
+  struct Ev {
+    const char *name;
+    double ts, dur;
+  };
+  struct Dev {
+    const char *name;
+    double ms;
+    int64_t n;
+  };
+  std::string path_;
+  std::chrono::steady_clock::time_point t0_;
+  int (*push_)(const char *) = nullptr;
+  int (*pop_)() = nullptr;
+  std::vector<Ev> events_;
+  std::vector<Dev> device_;
 };
 
 // ------------------------------------------------------------------ orthogonal init (train.cc:212-228)
@@ -471,6 +607,8 @@ int main(int argc, char **argv) {
   try {
     const auto start_time = std::chrono::system_clock::now().time_since_epoch().count();
     const std::string rom_path = argv[1], group = argv[4];
+    const std::string profile_path = argc > 6 ? argv[6] : ""; // train.cc:328-335
+    Profile prof(profile_path);
     std::string log_path = argv[2];
     { // replace_extension("tfevents.<start-time>") like train.cc:324-325
       const size_t slash = log_path.find_last_of('/'), dot = log_path.find_last_of('.');
@@ -492,6 +630,13 @@ int main(int argc, char **argv) {
     if (cfg.record_video)
       std::cerr << "note: record_video ignored (no ffmpeg / ALE in this build)\n";
 
+    if (const char *dump = std::getenv("ALEPPO_TRAINER_DUMP_INIT")) { // test hook: the initial parameters, no GPU needed
+      const std::vector<float> p = init_params(cfg.hidden_size, A, cfg.deterministic ? 42 : (uint64_t)start_time);
+      std::ofstream f(dump, std::ios::binary);
+      f.write(reinterpret_cast<const char *>(p.data()), (std::streamsize)(p.size() * sizeof(float)));
+      std::cout << "initial parameters written: " << p.size() << std::endl;
+      return 0;
+    }
     aleppo_config ac{};
     ac.abi_version = ALEPPO_ABI_VERSION;
     ac.device_ordinal = 0;
@@ -524,12 +669,33 @@ int main(int argc, char **argv) {
       check(ctx, aleppo_load_params(ctx, p.data(), p.size()));
     }
     EventWriter logger(log_path);
+    if (cfg.cuda_graph) // the reference's `cuda_graph: true`: replay the update loop as a captured graph
+      check(ctx, aleppo_set_option(ctx, ALEPPO_OPT_UPDATE_GRAPH, 1));
+    if (prof.on())
+      check(ctx, aleppo_profile_enable(ctx, 1));
+    logger.add_hparams( // get_parameters (train.cc:76-105), same keys
+        {{"total_environments", (double)cfg.total_environments}, {"hidden_size", (double)cfg.hidden_size},
+         {"action_size", (double)cfg.action_size}, {"horizon", (double)cfg.horizon}, {"max_steps", (double)cfg.max_steps},
+         {"frame_stack", (double)cfg.frame_stack}, {"learning_rate", cfg.learning_rate}, {"clip_param", cfg.clip_param},
+         {"value_loss_coef", cfg.value_loss_coef}, {"entropy_coef", cfg.entropy_coef},
+         {"num_epochs", (double)cfg.num_epochs}, {"mini_batch_size", (double)cfg.mini_batch_size},
+         {"num_mini_batches", (double)cfg.num_mini_batches}, {"gae_discount", cfg.gae_discount},
+         {"gae_lambda", cfg.gae_lambda}, {"max_gradient_norm", cfg.max_gradient_norm},
+         {"num_rollouts", (double)cfg.num_rollouts}, {"num_workers", (double)cfg.num_workers},
+         {"worker_batch_size", (double)cfg.worker_batch_size}, {"frame_skip", (double)cfg.frame_skip},
+         {"max_return", cfg.max_return}},
+        {{"record_observation", cfg.record_observation}, {"record_video", cfg.record_video},
+         {"cuda_graph", cfg.cuda_graph}, {"deterministic", cfg.deterministic}},
+        group, (double)start_time * 1e-9);
 
     // ---- Rollout host half (src/ai/rollout.cc)
     std::vector<SyntheticAtari> envs;
     for (size_t i = 0; i < E; ++i)
       envs.emplace_back(i + 0 /*seed arg of train.cc:380*/, cfg.max_steps, cfg.max_return, A);
-    std::vector<uint8_t> frames(E * 84 * 84), start_cpu(E, 1), term(E, 0), trunc(E, 0), game_over(E, 0);
+    // the workers' frame buffer: page-locked + GPU-mapped, read in place by the ingest kernel (see the file header)
+    uint8_t *frames = nullptr;
+    check(ctx, aleppo_host_alloc(ctx, E * 84 * 84, reinterpret_cast<void **>(&frames)));
+    std::vector<uint8_t> start_cpu(E, 1), term(E, 0), trunc(E, 0), game_over(E, 0);
     std::vector<float> rewards(E, 0.f), ep_ret(E, 0.f), game_ret(E, 0.f);
     std::vector<size_t> ep_len(E, 0), game_len(E, 0);
     std::vector<StepOut> results(E);
@@ -554,8 +720,14 @@ int main(int argc, char **argv) {
     auto rollout = [&]() {
       Log log;
       for (size_t t = 0; t < T; ++t) {
-        check(ctx, aleppo_act(ctx, nullptr, &actions));
-        pool.run_all(E);
+        {
+          Profile::Span sp(&prof, "aleppo_act");
+          check(ctx, aleppo_act(ctx, nullptr, &actions));
+        }
+        {
+          Profile::Span sp(&prof, "step_all (emulator threads)");
+          pool.run_all(E);
+        }
         std::vector<uint8_t> start_at_entry = start_cpu;
         for (size_t i = 0; i < E; ++i) {
           if (!start_cpu[i]) { // rollout.cc:214-226 (start slots keep the stale reward)
@@ -570,8 +742,11 @@ int main(int argc, char **argv) {
             total_steps++;
           }
         }
-        check(ctx, aleppo_step(ctx, frames.data(), ALEPPO_FRAMES_84, ALEPPO_HOST, rewards.data(), term.data(),
-                               trunc.data(), start_at_entry.data()));
+        {
+          Profile::Span sp(&prof, "aleppo_step");
+          check(ctx, aleppo_step(ctx, frames, ALEPPO_FRAMES_84, ALEPPO_HOST_MAPPED, rewards.data(), term.data(),
+                                 trunc.data(), start_at_entry.data()));
+        }
         for (size_t i = 0; i < E; ++i) { // rollout.cc:239-265
           if (results[i].terminated || results[i].truncated) {
             start_cpu[i] = 1;
@@ -592,7 +767,10 @@ int main(int argc, char **argv) {
           }
         }
       }
-      check(ctx, aleppo_finish_rollout(ctx, nullptr));
+      {
+        Profile::Span sp(&prof, "aleppo_finish_rollout");
+        check(ctx, aleppo_finish_rollout(ctx, nullptr));
+      }
       return log;
     };
 
@@ -603,16 +781,24 @@ int main(int argc, char **argv) {
       std::cout << "Rollout " << r + 1 << " of " << cfg.num_rollouts << std::endl;
       const double lr = cfg.learning_rate * (1.0 - r / static_cast<double>(cfg.num_rollouts)); // train.cc:424-428
       const Log log = rollout();
-      check(ctx, aleppo_train(ctx, lr, (int)cfg.num_epochs, (int)cfg.num_mini_batches, m.data()));
+      {
+        Profile::Span sp(&prof, "aleppo_train");
+        check(ctx, aleppo_train(ctx, lr, (int)cfg.num_epochs, (int)cfg.num_mini_batches, m.data()));
+      }
+      Profile::Span sp_log(&prof, "log_data");
       // log_data (train.cc:163-210): x axis = non-reset env steps
       const int64_t step = (int64_t)total_steps;
       if (!log.episode_returns.empty()) {
         logger.add_scalar("mean_episode_return", step, meanf(log.episode_returns));
         logger.add_scalar("mean_episode_length", step, meanf(log.episode_lengths));
         logger.add_histogram("episode_returns", step, log.episode_returns);
+        logger.add_histogram("episode_lengths", step,
+                             std::vector<float>(log.episode_lengths.begin(), log.episode_lengths.end()));
         if (!log.game_returns.empty()) {
           logger.add_scalar("mean_game_return", step, meanf(log.game_returns));
           logger.add_scalar("mean_game_length", step, meanf(log.game_lengths));
+          logger.add_histogram("game_returns", step, log.game_returns);
+          logger.add_histogram("game_lengths", step, std::vector<float>(log.game_lengths.begin(), log.game_lengths.end()));
         }
       }
       auto avg = [&](float aleppo_minibatch_metrics::*f) {
@@ -635,11 +821,48 @@ int main(int argc, char **argv) {
         if (gn.size() > 1)
           logger.add_histogram("clipped_gradients", step, gn);
       }
+      { // the per-sample histograms of log_data (train.cc:190-207): mask-selected values of the [epochs, M, B] planes
+        const size_t N = E * T, per = (size_t)cfg.num_epochs * N;
+        std::vector<uint8_t> masks(N);
+        std::vector<float> plane(per), adv(N), ret(N), sel;
+        check(ctx, aleppo_read_batch(ctx, ALEPPO_F_MASKS, masks.data(), N));
+        auto gather = [&](const std::vector<float> &x, size_t reps) { // gather(t, masks): unmasked entries, every epoch
+          sel.clear();
+          for (size_t r = 0; r < reps; ++r)
+            for (size_t i = 0; i < N; ++i)
+              if (masks[i])
+                sel.push_back(x[r * N + i]);
+          return sel;
+        };
+        const std::pair<int, const char *> fields[5] = {{ALEPPO_M_TOTAL_LOSSES, "losses"},
+                                                        {ALEPPO_M_CLIPPED_LOSSES, "clipped_losses"},
+                                                        {ALEPPO_M_VALUE_LOSSES, "value_losses"},
+                                                        {ALEPPO_M_ENTROPIES, "entropies"},
+                                                        {ALEPPO_M_RATIO, "ratios"}};
+        for (auto &fd : fields) {
+          check(ctx, aleppo_read_train_metric(ctx, fd.first, plane.data(), per));
+          logger.add_histogram(fd.second, step, gather(plane, (size_t)cfg.num_epochs));
+        }
+        check(ctx, aleppo_read_batch(ctx, ALEPPO_F_ADVANTAGES, adv.data(), N * 4));
+        check(ctx, aleppo_read_batch(ctx, ALEPPO_F_RETURNS, ret.data(), N * 4));
+        logger.add_histogram("advantages", step, gather(adv, 1));
+        logger.add_histogram("returns", step, gather(ret, 1));
+      }
       logger.flush();
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    std::cout << "steps " << total_steps << " episodes " << episodes << " env-steps/s "
-              << (double)(cfg.num_rollouts * E * T) / secs << std::endl;
+    size_t pending_starts = 0; // environments whose next slot is an episode-start slot
+    for (size_t i = 0; i < E; ++i)
+      pending_starts += start_cpu[i];
+    // total_steps counts only non-start slots (rollout.cc:225,266): slots = steps + start slots, and the start slots are
+    // the E initial ones plus one per finished episode, minus those still pending
+    std::cout << "steps " << total_steps << " episodes " << episodes << " pending_starts " << pending_starts << " slots "
+              << (cfg.num_rollouts + 1) * E * T << " env-steps/s " << (double)(cfg.num_rollouts * E * T) / secs << std::endl;
+    if (prof.on()) {
+      prof.device_summary(ctx);
+      prof.save();
+    }
+    check(ctx, aleppo_host_free(ctx, frames));
     aleppo_destroy(ctx);
     std::cout << "Success" << std::endl;
     return 0;
