@@ -32,6 +32,7 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fc_pipe_wgrad = flag("ALEPPO_FC_PIPE_WGRAD", false);
+  t.fuse_c2d_c1w = flag("ALEPPO_FUSE_C2D_C1W", true);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -1000,9 +1001,19 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
       prof_end(c, ALEPPO_K_CONV3_WGRAD, sw);
       HIPCHK(c, fork(c->ev_dz2)); // dz2 is ready
-      prof_begin(c, ALEPPO_K_CONV2_DGRAD);
-      conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
-      prof_end(c, ALEPPO_K_CONV2_DGRAD);
+      // bf16: conv2's data gradient and conv1's weight gradient run as ONE launch (conv_fuse.hpp): dz1 goes from the
+      // dgrad's accumulators through LDS into the wgrad's MFMAs and never reaches HBM
+      const bool fuse21 = prec == ALEPPO_BF16 && use_patch_kernels() && c->tune.fuse_c2d_c1w;
+      int S1 = 0;
+      if (fuse21) {
+        prof_begin(c, ALEPPO_K_CONV2D_CONV1W);
+        S1 = patch_conv2_dgrad_conv1_wgrad(s, c->dz2, c->W2d, c->a1, c->obs, map, sW1, sB1, B);
+        prof_end(c, ALEPPO_K_CONV2D_CONV1W);
+      } else {
+        prof_begin(c, ALEPPO_K_CONV2_DGRAD);
+        conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
+        prof_end(c, ALEPPO_K_CONV2_DGRAD);
+      }
       prof_begin(c, ALEPPO_K_CONV2_WGRAD, sw);
       const int S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
       prof_end(c, ALEPPO_K_CONV2_WGRAD, sw);
@@ -1021,9 +1032,11 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         prof_end(c, ALEPPO_K_REDUCE, sw);
         nseg = 0;
       }
-      prof_begin(c, ALEPPO_K_CONV1_WGRAD);
-      const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
-      prof_end(c, ALEPPO_K_CONV1_WGRAD);
+      if (!fuse21) {
+        prof_begin(c, ALEPPO_K_CONV1_WGRAD);
+        S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
+        prof_end(c, ALEPPO_K_CONV1_WGRAD);
+      }
       if (two) { // join: sumsq / Adam read the whole gradient
         HIPCHK(c, hipEventRecord(c->ev_wg, sw));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_wg, 0));
@@ -1381,6 +1394,8 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->tune.fc_pipe = value != 0;
   else if (option == ALEPPO_OPT_FC_PIPE_WGRAD)
     c->tune.fc_pipe_wgrad = value != 0;
+  else if (option == ALEPPO_OPT_FUSE_C2D_C1W)
+    c->tune.fuse_c2d_c1w = value != 0;
   else if (option == ALEPPO_OPT_FUSED_ACT)
     c->tune.fused_act = value; // 0: never, 1: where it is faster (default), 2: always
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
@@ -1407,6 +1422,7 @@ extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
   case ALEPPO_OPT_FC_PIPE: *value = c->tune.fc_pipe; break;
   case ALEPPO_OPT_FC_PIPE_WGRAD: *value = c->tune.fc_pipe_wgrad; break;
   case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
+  case ALEPPO_OPT_FUSE_C2D_C1W: *value = c->tune.fuse_c2d_c1w; break;
   case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
   default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
   }

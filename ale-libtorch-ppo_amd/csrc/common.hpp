@@ -61,6 +61,7 @@ struct Tuning {
   bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
   bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
   bool fc_pipe_wgrad = false; // opt-in pipelined fc wgrad
+  bool fuse_c2d_c1w = true;   // conv2 dgrad + conv1 wgrad in one launch (dz1 never leaves the CU)
   int fused_act = 1;          // frame ingest fused in front of the acting convolutions: 0 never, 1 where faster, 2 always
 };
 const Tuning &tuning();
@@ -279,6 +280,8 @@ void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns);
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns);
+int patch_conv2_dgrad_conv1_wgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, const uint32_t *obs,
+                                  SampleMap map, float *sw, float *sb, long ns);
 int patch_conv3_wgrad(hipStream_t s, const void *dz3, const void *a2, float *sw, float *sb, long ns);
 
 } // namespace aleppo

@@ -3,6 +3,7 @@
 #include "common.hpp"
 #include "conv_patch.hpp"
 #include "conv3_tile.hpp"
+#include "conv_fuse.hpp"
 #include <cstdlib>
 
 namespace aleppo {
@@ -143,6 +144,20 @@ int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, Sampl
                       long ns) {
   WgradParams P{obs, static_cast<const bf16 *>(dz1), sw, sb, ns, map, 1.0f / 255.0f};
   return launch_wgrad<LConv1Wgrad>(s, P);
+}
+// conv2 dgrad + conv1 wgrad in one launch (conv_fuse.hpp); returns the number of slabs written
+int patch_conv2_dgrad_conv1_wgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, const uint32_t *obs,
+                                  SampleMap map, float *sw, float *sb, long ns) {
+  static bool once = false;
+  if (!once) {
+    allow_smem(conv2_dgrad_conv1_wgrad_kernel, F21_SMEM);
+    once = true;
+  }
+  FuseC2dC1wParams P{static_cast<const bf16 *>(dz2), static_cast<const bf16 *>(W2d), static_cast<const bf16 *>(a1),
+                     reinterpret_cast<const uint8_t *>(obs), map, sw, sb, ns, 1.0f / 255.0f};
+  const int grid = (int)std::min<long>(ns, std::min(num_cus(), MAXS_C1));
+  hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel, dim3(grid), dim3(512), F21_SMEM, s, P);
+  return grid;
 }
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns) {
   WgradParams P{a1, static_cast<const bf16 *>(dz2), sw, sb, ns, SampleMap{1, 0, 0, 0, 0}, 1.0f};

@@ -28,7 +28,7 @@ from __graft_entry__ import load_package  # noqa: E402
 KFLOP = dict(conv1_fwd=2 * 400 * 32 * 256, conv2_fwd=2 * 81 * 64 * 512, conv3_fwd=2 * 49 * 64 * 576,
              fc_fwd=2 * 3136 * 512, fc_dgrad=2 * 3136 * 512, fc_wgrad=2 * 3136 * 512, conv3_dgrad=2 * 49 * 64 * 576,
              conv3_wgrad=2 * 49 * 64 * 576, conv2_dgrad=2 * 81 * 64 * 512, conv2_wgrad=2 * 81 * 64 * 512,
-             conv1_wgrad=2 * 400 * 32 * 256)
+             conv1_wgrad=2 * 400 * 32 * 256, conv2d_conv1w=2 * 81 * 64 * 512 + 2 * 400 * 32 * 256)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -41,7 +41,8 @@ def kernel_bytes(dtype):
     dh = 512 * e
     return dict(conv1_fwd=obs + a1, conv2_fwd=a1 + a2, conv3_fwd=a2 + a3, fc_fwd=a3 + h, fc_dgrad=dh + 2 * a3,
                 fc_wgrad=dh + a3, conv3_dgrad=a3 + 2 * a2, conv3_wgrad=a3 + a2, conv2_dgrad=a2 + 2 * a1,
-                conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs)
+                conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs,
+                conv2d_conv1w=a2 + a1 + obs)  # fused: dz2 + ReLU gates a1 + packed observation in, nothing but slabs out
 
 
 def log(msg):

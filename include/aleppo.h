@@ -274,7 +274,8 @@ typedef enum {
   ALEPPO_K_REDUCE = 15,     /* split-K slab reduction */
   ALEPPO_K_INFER_HEAD = 16, /* action head + sampling */
   ALEPPO_K_ACT_FUSED = 17,  /* frame ingest + conv1-3 of the acting batch in one launch (aleppo_step, bf16) */
-  ALEPPO_K_COUNT = 18
+  ALEPPO_K_CONV2D_CONV1W = 18, /* conv2 dgrad + conv1 wgrad in one launch (bf16; replaces classes 12 and 14) */
+  ALEPPO_K_COUNT = 19
 } aleppo_kernel_class;
 int aleppo_profile_enable(aleppo_ctx *ctx, int on);
 int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);
@@ -291,6 +292,7 @@ typedef enum {
   ALEPPO_OPT_FC_PIPE_WGRAD = 5,    /* 1: pipelined fc weight gradient (opt-in, measured slower) */
   ALEPPO_OPT_FUSED_ACT = 6,        /* frame ingest fused in front of the acting convolutions (bf16): 0 never, 1 where it
                                       is faster (default: given 84x84 frames, raw pairs in mapped host memory), 2 always */
+  ALEPPO_OPT_FUSE_C2D_C1W = 8,     /* 0: conv2 dgrad and conv1 wgrad as two launches with dz1 in HBM (A/B, parity tests) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */
