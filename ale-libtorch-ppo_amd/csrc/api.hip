@@ -32,7 +32,7 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fc_pipe_wgrad = flag("ALEPPO_FC_PIPE_WGRAD", false);
-  t.fuse_c2d_c1w = flag("ALEPPO_FUSE_C2D_C1W", true);
+  t.fuse_c2d_c1w = flag("ALEPPO_FUSE_C2D_C1W", false);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;

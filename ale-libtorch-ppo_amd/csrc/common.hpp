@@ -61,7 +61,10 @@ struct Tuning {
   bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
   bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
   bool fc_pipe_wgrad = false; // opt-in pipelined fc wgrad
-  bool fuse_c2d_c1w = true;   // conv2 dgrad + conv1 wgrad in one launch (dz1 never leaves the CU)
+  // conv2 dgrad + conv1 wgrad in one launch (dz1 never leaves the CU): 210 MB less HBM traffic per 4096-sample minibatch and
+  // 111 us instead of 55 + 68 us alone on the GPU, but its 111 KB of LDS keeps conv2's weight-gradient kernel (co-scheduled
+  // on the second stream) off the same CU: 7.90 vs 7.80 ms per update in the timed two-stream schedule -> opt-in
+  bool fuse_c2d_c1w = false;
   int fused_act = 1;          // frame ingest fused in front of the acting convolutions: 0 never, 1 where faster, 2 always
 };
 const Tuning &tuning();

@@ -292,7 +292,8 @@ typedef enum {
   ALEPPO_OPT_FC_PIPE_WGRAD = 5,    /* 1: pipelined fc weight gradient (opt-in, measured slower) */
   ALEPPO_OPT_FUSED_ACT = 6,        /* frame ingest fused in front of the acting convolutions (bf16): 0 never, 1 where it
                                       is faster (default: given 84x84 frames, raw pairs in mapped host memory), 2 always */
-  ALEPPO_OPT_FUSE_C2D_C1W = 8,     /* 0: conv2 dgrad and conv1 wgrad as two launches with dz1 in HBM (A/B, parity tests) */
+  ALEPPO_OPT_FUSE_C2D_C1W = 8,     /* 1: conv2 dgrad + conv1 wgrad as ONE launch, dz1 never reaches HBM (opt-in: less traffic,
+                                      faster alone, slower beside the co-scheduled conv2 wgrad) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */
