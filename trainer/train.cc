@@ -24,8 +24,13 @@
 // VirtualEnvironment-like interface is a deterministic synthetic Atari-shaped game (84x84 gray frames,
 // 5 lives, reward on "brick hits", terminal on life loss like EpisodeLife, truncation at max_steps /
 // max_return).  The rom argument is accepted and recorded but not opened.
-// New OPTIONAL yaml keys (defaults reproduce the reference): precision: fp32|bf16, advantage_norm: false,
-// action_size (honoured here; the reference hard-codes 4, Q4), seed.
+// New OPTIONAL yaml keys (defaults reproduce the reference): precision: fp32|bf16, rollout_precision: fp32|fp16,
+// advantage_norm: false, action_size (honoured here; the reference hard-codes 4, Q4), seed.
+// Data parallelism (no reference counterpart): start one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK
+// in the environment (torchrun / mpirun style).  Rank r owns the contiguous environment block
+// [r * E / W, (r + 1) * E / W) and GPU LOCAL_RANK; rank 0 creates the RCCL id, hands it to the others through the file
+// <log path>.rcclid, and is the only rank that writes the event file (its own environments' episode statistics, the
+// global - all-reduced - update metrics).  Everything else is unchanged: aleppo_train all-reduces the gradients.
 #include "../include/aleppo.h"
 #include <algorithm>
 #include <atomic>
@@ -62,7 +67,7 @@ struct Config {
   float max_return = -1.0f;
   bool record_observation = false, record_video = false, cuda_graph = false, deterministic = false;
   // extensions
-  std::string precision = "fp32";
+  std::string precision = "fp32", rollout_precision = "fp32";
   bool advantage_norm = false;
   uint64_t seed = 42;
 };
@@ -137,6 +142,7 @@ static Config load_config(const std::string &path) { // keys / defaults of src/b
   c.cuda_graph = as_bool(kv, "cuda_graph", false);
   c.deterministic = as_bool(kv, "deterministic", false);
   c.precision = as<std::string>(kv, "precision", "fp32");
+  c.rollout_precision = as<std::string>(kv, "rollout_precision", "fp32");
   c.advantage_norm = as_bool(kv, "advantage_norm", false);
   c.seed = as<uint64_t>(kv, "seed", 42);
   return c;
@@ -622,7 +628,17 @@ int main(int argc, char **argv) {
       if (!parent.empty() && !std::filesystem::exists(parent))
         std::filesystem::create_directories(parent);
     }
-    const size_t E = cfg.total_environments, T = cfg.horizon, A = cfg.action_size;
+    auto env_int = [](const char *k, int dflt) {
+      const char *v = std::getenv(k);
+      return v ? std::atoi(v) : dflt;
+    };
+    const int world = std::max(1, env_int("WORLD_SIZE", 1)), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", rank);
+    if (rank < 0 || rank >= world)
+      throw std::runtime_error("RANK must be in [0, WORLD_SIZE)");
+    if (cfg.total_environments % (size_t)world)
+      throw std::runtime_error("total_environments must be divisible by WORLD_SIZE");
+    const size_t E = cfg.total_environments / (size_t)world, T = cfg.horizon, A = cfg.action_size; // E: THIS rank's envs
+    const size_t env0 = (size_t)rank * E;                                                           // its first environment
     if ((E * T) % (size_t)cfg.num_mini_batches)
       throw std::runtime_error("Batch size must be divisible by num_mini_batches");
     if (E % cfg.worker_batch_size)
@@ -639,15 +655,16 @@ int main(int argc, char **argv) {
     }
     aleppo_config ac{};
     ac.abi_version = ALEPPO_ABI_VERSION;
-    ac.device_ordinal = 0;
-    ac.world_size = 1;
-    ac.rank = 0;
+    ac.device_ordinal = local_rank;
+    ac.world_size = world;
+    ac.rank = rank;
     ac.num_envs = (int32_t)E;
     ac.horizon = (int32_t)T;
     ac.num_actions = (int32_t)A;
     ac.hidden_size = (int32_t)cfg.hidden_size;
     ac.frame_stack = (int32_t)cfg.frame_stack;
     ac.precision = cfg.precision == "bf16" ? ALEPPO_BF16 : ALEPPO_FP32;
+    ac.rollout_precision = cfg.rollout_precision == "fp16" ? ALEPPO_ROLLOUT_FP16 : ALEPPO_ROLLOUT_FP32;
     ac.advantage_norm = cfg.advantage_norm;
     ac.gamma = cfg.gae_discount;
     ac.lambda = cfg.gae_lambda;
@@ -660,6 +677,30 @@ int main(int argc, char **argv) {
     check(nullptr, aleppo_create(&ac, &ctx));
     std::cout << "MI355X is available! Training on GPU (rom argument '" << rom_path << "' -> synthetic emulator)."
               << std::endl;
+    if (world > 1) { // RCCL communicator: rank 0's 128-byte id travels through a file next to the log
+      const std::string idfile = std::string(argv[2]) + ".rcclid";
+      uint8_t id[ALEPPO_UNIQUE_ID_BYTES];
+      if (rank == 0) {
+        check(nullptr, aleppo_comm_unique_id(id));
+        {
+          std::ofstream f(idfile + ".tmp", std::ios::binary);
+          f.write(reinterpret_cast<const char *>(id), sizeof(id));
+        }
+        std::filesystem::rename(idfile + ".tmp", idfile);
+      } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+          std::ifstream f(idfile, std::ios::binary);
+          if (f && f.read(reinterpret_cast<char *>(id), sizeof(id)))
+            break;
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300))
+            throw std::runtime_error("timed out waiting for " + idfile);
+          std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+      }
+      check(ctx, aleppo_comm_init(ctx, id));
+      std::cout << "rank " << rank << " of " << world << ": environments [" << env0 << ", " << env0 + E << ")" << std::endl;
+    }
     {
       const std::vector<float> p = init_params(cfg.hidden_size, A, cfg.deterministic ? 42 : (uint64_t)start_time);
       size_t n = 0;
@@ -668,7 +709,7 @@ int main(int argc, char **argv) {
         throw std::runtime_error("parameter count mismatch");
       check(ctx, aleppo_load_params(ctx, p.data(), p.size()));
     }
-    EventWriter logger(log_path);
+    EventWriter logger(rank == 0 ? log_path : log_path + ".rank" + std::to_string(rank)); // rank 0's file is THE log
     if (cfg.cuda_graph) // the reference's `cuda_graph: true`: replay the update loop as a captured graph
       check(ctx, aleppo_set_option(ctx, ALEPPO_OPT_UPDATE_GRAPH, 1));
     if (prof.on())
@@ -691,7 +732,7 @@ int main(int argc, char **argv) {
     // ---- Rollout host half (src/ai/rollout.cc)
     std::vector<SyntheticAtari> envs;
     for (size_t i = 0; i < E; ++i)
-      envs.emplace_back(i + 0 /*seed arg of train.cc:380*/, cfg.max_steps, cfg.max_return, A);
+      envs.emplace_back(env0 + i + 0 /*seed arg of train.cc:380*/, cfg.max_steps, cfg.max_return, A);
     // the workers' frame buffer: page-locked + GPU-mapped, read in place by the ingest kernel (see the file header)
     uint8_t *frames = nullptr;
     check(ctx, aleppo_host_alloc(ctx, E * 84 * 84, reinterpret_cast<void **>(&frames)));
