@@ -22,7 +22,8 @@ from types import SimpleNamespace
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaleppo.so")
+# (ALEPPO_LIB_PATH: developer A/B runs of two builds inside one gpurun call; never set by tests or bench)
+LIB_PATH = os.environ.get("ALEPPO_LIB_PATH") or os.path.join(_HERE, "libaleppo.so")
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4

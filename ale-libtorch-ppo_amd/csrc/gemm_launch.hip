@@ -245,8 +245,55 @@ template <class T> static void fc_fwd_splitk_t(hipStream_t s, const void *a3, co
   hipLaunchKernelGGL((gemm_nt_kernel<T, AL, BL, EP, 32, 32, 2, 2>), grid2(ns, 32, H, 32, FC_SPLITS), dim3(256), 0, s,
                      ap, bp, ep, (int)ns, H, KC);
 }
+// bf16 acting fc, latency form.  At acting size (128 rows) the GEMM is a dependency chain, not a throughput problem: the
+// staged kernel above walks 7 k-stages per workgroup, i.e. ~4 dependent L2 / HBM round trips behind the conv kernel that
+// just wrote a3 on another XCD.  Here a workgroup requests its WHOLE 32 x 448 operand slabs up front (14 coalesced
+// 16-byte loads per thread, all in flight together), stages them in LDS once (57 KB, one barrier) and runs its 14 k-steps
+// out of LDS: one memory round trip per launch.  (Loading the MFMA fragments straight from global memory - no LDS - was
+// slower than the staged kernel: 64-byte row segments, 28 vector-memory instructions per wave: 10.5 vs 8.0 us.)
+__global__ __launch_bounds__(256) void fc_act_kernel(const bf16 *__restrict__ a3, const bf16 *__restrict__ Wfc,
+                                                     float *__restrict__ hpart, int M, int N) {
+  constexpr int KC = FC_IN / FC_SPLITS, KS = KC / 32, VPR = KC / 8; // 448 deep: 14 MFMA k-steps, 56 vectors per row
+  constexpr int ROWV = VPR + 1;                                     // LDS row pitch in 16-byte vectors (912 B: +16 B pad)
+  constexpr int NV = 32 * VPR / 256;                                // 7 vectors per thread and operand
+  __shared__ u32x4 sA[32 * ROWV], sB[32 * ROWV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1, z = blockIdx.z;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  u32x4 ra[NV], rb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { // vector v = tid + 256 i: row v / 56, chunk v % 56 (rows past the end: clamped, masked below)
+    const int v = tid + 256 * i, r = v / VPR, c = v - r * VPR;
+    ra[i] = *reinterpret_cast<const u32x4 *>(a3 + (long)min(m0 + r, M - 1) * FC_IN + z * KC + c * 8);
+    rb[i] = *reinterpret_cast<const u32x4 *>(Wfc + (long)min(n0 + r, N - 1) * FC_IN + z * KC + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + 256 * i, r = v / VPR, c = v - r * VPR;
+    sA[r * ROWV + c] = ra[i];
+    sB[r * ROWV + c] = rb[i];
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    Atom<bf16>::mma(sA[(wm * 16 + fr) * ROWV + ks * 4 + fg], sB[(wn * 16 + fr) * ROWV + ks * 4 + fg], acc);
+  // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+  float *out = hpart + (long)z * M * N;
+  const int nn = n0 + wn * 16 + fr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mm = m0 + wm * 16 + fg * 4 + r;
+    if (mm < M && nn < N)
+      out[(long)mm * N + nn] = acc[r];
+  }
+}
 void fc_fwd_splitk(hipStream_t s, int prec, const void *a3, const void *Wfc, float *hpart, long ns, int H) {
-  if (prec == ALEPPO_BF16)
+  static const bool latency_form = tune("ALEPPO_FC_ACT_LATENCY", 1) != 0; // A/B switch
+  if (prec == ALEPPO_BF16 && latency_form)
+    hipLaunchKernelGGL(fc_act_kernel, grid2(ns, 32, H, 32, FC_SPLITS), dim3(256), 0, s, static_cast<const bf16 *>(a3),
+                       static_cast<const bf16 *>(Wfc), hpart, (int)ns, H);
+  else if (prec == ALEPPO_BF16)
     fc_fwd_splitk_t<bf16>(s, a3, Wfc, hpart, ns, H);
   else
     fc_fwd_splitk_t<float>(s, a3, Wfc, hpart, ns, H);
