@@ -778,17 +778,17 @@ template <class L> constexpr size_t conv_patch_smem() {
 struct LConv1Wgrad { // half-sample units like LConv1Fwd
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OC = 32, NJ = 256,
-                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, PF2 = 1; // wave: 2 oc x 2 of 16 j atoms
+                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, PF2 = 1, SPEC = 1; // wave: 2 oc x 2 of 16 j atoms
 };
 struct LConv2Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OC = 64, NJ = 512, SB = 1,
-                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40, PF2 = 0; // wave: all 4 oc atoms x 4 of the 32 j atoms
+                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40, PF2 = 0, SPEC = 0; // wave: all 4 oc atoms x 4 of the 32 j atoms
 };
 struct LConv3Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OC = 64, NJ = 576, SB = 3,
-                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80, PF2 = 0; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
+                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80, PF2 = 0, SPEC = 0; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
 };
 
 struct WgradParams {
@@ -812,22 +812,33 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   constexpr int X_ELEMS = (L::SB * LPATCH + 63) / 64 * 64;
   constexpr int DY_ELEMS = KS * 32 * DYS;
   constexpr int BUF_ELEMS = X_ELEMS + DY_ELEMS;
-  constexpr int XV = L::SB * PATCH * (int)sizeof(InT) / 16, NXV = (XV + 511) / 512;
-  constexpr int DV = KPIX * L::OC / 8, NDV = (DV + 511) / 512; // dY source vectors (8 bf16)
+  // SPEC: wave specialisation.  Waves 0-3 (one per SIMD) are PRODUCERS - they prefetch, widen / stage both operands and
+  // keep the bias sums - waves 4-7 are CONSUMERS that own the whole dW tile between them (twice the columns each) and
+  // issue nothing but fragment reads and MFMAs.  With every wave doing both jobs in lockstep the vector pipe (staging)
+  // and the matrix pipe took turns, barrier to barrier; a producer and a consumer wave on the same SIMD use them at the
+  // same time, and a group lasts max(staging, multiply) instead of their sum.
+  constexpr bool SP = L::SPEC != 0;
+  constexpr int NPROD = SP ? 256 : 512; // threads that stage
+  constexpr int NI = SP ? 2 * L::NI : L::NI;
+  constexpr int XV = L::SB * PATCH * (int)sizeof(InT) / 16, NXV = (XV + NPROD - 1) / NPROD;
+  constexpr int DV = KPIX * L::OC / 8, NDV = (DV + NPROD - 1) / NPROD; // dY source vectors (8 bf16)
   constexpr int VPR = L::OC / 8;                  // dY vectors per pixel row
   constexpr int SEG = L::KW * L::C;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16 *sbuf = reinterpret_cast<bf16 *>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave % L::WM, wn = wave / L::WM;
+  const bool producer = !SP || wave < 4, consumer = !SP || wave >= 4;
+  const int cw = SP ? (wave & 3) : wave; // consumer index
+  const int wm = cw % L::WM, wn = cw / L::WM;
   const int li = lane & 15, lg = lane >> 4;
+  static_assert(!SP || L::WM == 1, "specialised form: consumers split the columns only");
 
-  f32x4 acc[L::MI][L::NI];
+  f32x4 acc[L::MI][NI];
 #pragma unroll
   for (int i = 0; i < L::MI; ++i)
 #pragma unroll
-    for (int j = 0; j < L::NI; ++j)
+    for (int j = 0; j < NI; ++j)
       acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // this thread's 8 fixed channels (tid % VPR)
 
@@ -844,10 +855,10 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
       const int s = q / L::PIX, p = q - s * L::PIX, oy = p / L::OW, ox = p - oy * L::OW;
       pixoff[ks][r] = s * LPATCH + ((oy * L::S) * L::IW + ox * L::S) * L::CP;
     }
-  int joff[L::NI]; // column part: j = 16*(atom) + 4(li&3) -> (kh, kw, c)
+  int joff[NI]; // column part: j = 16*(atom) + 4(li&3) -> (kh, kw, c)
 #pragma unroll
-  for (int j = 0; j < L::NI; ++j) {
-    const int jj = (wn * L::NI + j) * 16 + 4 * (li & 3);
+  for (int j = 0; j < NI; ++j) {
+    const int jj = (wn * NI + j) * 16 + 4 * (li & 3);
     joff[j] = ((jj / SEG) * L::IW + (jj % SEG) / L::C) * L::CP + jj % L::C;
   }
 
@@ -867,7 +878,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     const long n0 = min(grp, ngroups - 1) * L::SB;
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
-      const int v = min(tid + 512 * i, XV - 1);
+      const int v = min(tid + NPROD * i, XV - 1);
       if constexpr (U8) {
         const long n = n0 / L::GPS + P.map.n0;
         const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base;
@@ -880,7 +891,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     }
 #pragma unroll
     for (int i = 0; i < NDV; ++i) {
-      const int v = min(tid + 512 * i, DV - 1);
+      const int v = min(tid + NPROD * i, DV - 1);
       const long u = min(n0 + (v / VPR) / L::PIX, nunits - 1);
       RD[i] = reinterpret_cast<const u32x4 *>(P.dy + u * (long)(L::PIX * L::OC))[v % (L::PIX * VPR)];
     }
@@ -893,7 +904,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     const long u0 = grp * L::SB;
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
-      const int v = tid + 512 * i;
+      const int v = tid + NPROD * i;
       if (v < XV) {
         if (u0 + v / (XV / L::SB) >= nunits)
           RX[i] = zero16();
@@ -916,7 +927,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     }
 #pragma unroll
     for (int i = 0; i < NDV; ++i) {
-      const int v = tid + 512 * i;
+      const int v = tid + NPROD * i;
       if (v < DV) {
         const int row = v / VPR, cv = v - row * VPR;
         if (u0 + row / L::PIX >= nunits)
@@ -940,12 +951,12 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     const bf16 *px = sbuf + (size_t)buf * BUF_ELEMS, *pd = px + X_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      u32x4 fa[L::MI], fb[L::NI];
+      u32x4 fa[L::MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < L::MI; ++i)
         fa[i] = KFrag<bf16>::read(pd, DYS, ks * 32, (wm * L::MI + i) * 16, lane);
 #pragma unroll
-      for (int j = 0; j < L::NI; ++j) {
+      for (int j = 0; j < NI; ++j) {
         const u32x2 lo = __builtin_bit_cast(
             u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(px + pixoff[ks][0] + joff[j])));
         const u32x2 hi = __builtin_bit_cast(
@@ -955,7 +966,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
 #pragma unroll
       for (int i = 0; i < L::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < L::NI; ++j)
+        for (int j = 0; j < NI; ++j)
           Atom<bf16>::mma(fa[i], fb[j], acc[i][j]);
     }
   };
@@ -964,19 +975,27 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   const long gs = gridDim.x;
   long grp = blockIdx.x;
   if constexpr (L::PF2 != 0) {
-    gload(R0, grp);
-    gload(R1, grp + gs);
-    swrite(R0, 0, grp);
-    gload(R0, grp + 2 * gs);
+    if (producer) {
+      gload(R0, grp);
+      gload(R1, grp + gs);
+      swrite(R0, 0, grp);
+      gload(R0, grp + 2 * gs);
+    }
     __syncthreads();
-    for (; grp < ngroups; grp += 2 * gs) {
-      multiply(0);
-      swrite(R1, 1, grp + gs);
-      gload(R1, grp + 3 * gs);
+    for (; grp < ngroups; grp += 2 * gs) { // (roles are wave-uniform: a wave runs one branch with EXEC all ones)
+      if (consumer)
+        multiply(0);
+      if (producer) {
+        swrite(R1, 1, grp + gs);
+        gload(R1, grp + 3 * gs);
+      }
       __syncthreads();
-      multiply(1); // (a group past the end was staged as zeros: adds nothing)
-      swrite(R0, 0, grp + 2 * gs);
-      gload(R0, grp + 4 * gs);
+      if (consumer)
+        multiply(1); // (a group past the end was staged as zeros: adds nothing)
+      if (producer) {
+        swrite(R0, 0, grp + 2 * gs);
+        gload(R0, grp + 4 * gs);
+      }
       __syncthreads();
     }
   } else { // one group ahead (conv2 / conv3: a second register set would spill)
@@ -999,8 +1018,9 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
     for (int r = 0; r < 4; ++r) {
       const int m = (wm * L::MI + i) * 16 + lg * 4 + r;
 #pragma unroll
-      for (int j = 0; j < L::NI; ++j)
-        ow[(long)m * L::NJ + (wn * L::NI + j) * 16 + li] = acc[i][j][r] * P.scale;
+      for (int j = 0; j < NI; ++j)
+        if (consumer)
+          ow[(long)m * L::NJ + (wn * NI + j) * 16 + li] = acc[i][j][r] * P.scale;
     }
   // bias: threads with equal tid % VPR hold the same 8 channels; ordered LDS reduction (deterministic)
   __syncthreads();
