@@ -67,3 +67,28 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "oracle/" not in txt.replace(
                     "``oracle/``", ""), f
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py --gpus N under a launcher with a different WORLD_SIZE exits before touching torch or a GPU (ADVICE r1);
+    without a launcher and N > 1 it would spawn torch.distributed.run itself (not exercised here: no GPUs)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_option_and_location_constants_match_the_header(pkg):
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aleppo.h")).read(), flags=re.S)
+    for name, val in (("ALEPPO_OPT_GENERIC_CONV", pkg.OPT_GENERIC_CONV), ("ALEPPO_OPT_FC_PIPE", pkg.OPT_FC_PIPE),
+                      ("ALEPPO_OPT_FC_PIPE_WGRAD", pkg.OPT_FC_PIPE_WGRAD), ("ALEPPO_OPT_FUSED_ACT", pkg.OPT_FUSED_ACT),
+                      ("ALEPPO_OPT_UPDATE_GRAPH", pkg.OPT_UPDATE_GRAPH), ("ALEPPO_OPT_FUSE_C2D_C1W", pkg.OPT_FUSE_C2D_C1W),
+                      ("ALEPPO_OPT_SERIAL_UPDATE", pkg.OPT_SERIAL_UPDATE), ("ALEPPO_OPT_FORCE_COMM", pkg.OPT_FORCE_COMM),
+                      ("ALEPPO_HOST_MAPPED", pkg.HOST_MAPPED), ("ALEPPO_ROLLOUT_FP16", pkg.ROLLOUT_FP16),
+                      ("ALEPPO_ABI_VERSION", pkg.ABI_VERSION)):
+        m = re.search(rf"\b{name}\s*=?\s*(\d+)", txt)
+        assert m and int(m.group(1)) == val, name
+    kc = re.search(r"ALEPPO_K_COUNT = (\d+)", txt)
+    assert int(kc.group(1)) == len(pkg.KERNEL_CLASSES)
