@@ -105,13 +105,15 @@ def test_orthogonal_init_property(trainer, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16+fp16planes+graph"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16+fp16planes+graph", "fp32+rawframes"])
 def test_trains_debug_config_and_writes_event_file(trainer, tmp_path, precision):
     cfg = tmp_path / "debug.yaml"
     txt = open(os.path.join(ROOT, "trainer", "configs", "debug.yaml")).read().replace("num_rollouts: 10",
                                                                                       "num_rollouts: 4")
-    if "+" in precision:  # the optional keys: half-precision rollout planes, the update as a captured graph
+    if "graph" in precision:  # the optional keys: half-precision rollout planes, the update as a captured graph
         txt = txt.replace("cuda_graph: false", "cuda_graph: true") + "rollout_precision: fp16\n"
+    if "rawframes" in precision:  # N2: raw 210x160 frame pairs from the emulator threads, preprocessing on the device
+        txt += "device_preprocess: true\n"
     cfg.write_text(txt.replace("precision: fp32", f"precision: {precision.split('+')[0]}"))
     log = tmp_path / "tb" / "run.log"
     os.makedirs(log.parent)

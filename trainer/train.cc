@@ -25,7 +25,8 @@
 // 5 lives, reward on "brick hits", terminal on life loss like EpisodeLife, truncation at max_steps /
 // max_return).  The rom argument is accepted and recorded but not opened.
 // New OPTIONAL yaml keys (defaults reproduce the reference): precision: fp32|bf16, rollout_precision: fp32|fp16,
-// advantage_norm: false, action_size (honoured here; the reference hard-codes 4, Q4), seed.
+// device_preprocess: false (true: the emulators hand over RAW 210x160 frame pairs and the device does gray LUT + resize +
+// max), advantage_norm: false, action_size (honoured here; the reference hard-codes 4, Q4), seed.
 // Data parallelism (no reference counterpart): start one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK
 // in the environment (torchrun / mpirun style).  Rank r owns the contiguous environment block
 // [r * E / W, (r + 1) * E / W) and GPU LOCAL_RANK; rank 0 creates the RCCL id, hands it to the others through the file
@@ -68,6 +69,7 @@ struct Config {
   bool record_observation = false, record_video = false, cuda_graph = false, deterministic = false;
   // extensions
   std::string precision = "fp32", rollout_precision = "fp32";
+  bool device_preprocess = false; // emulators hand over raw frame pairs; gray LUT + resize + max run on the device (N2)
   bool advantage_norm = false;
   uint64_t seed = 42;
 };
@@ -143,6 +145,7 @@ static Config load_config(const std::string &path) { // keys / defaults of src/b
   c.deterministic = as_bool(kv, "deterministic", false);
   c.precision = as<std::string>(kv, "precision", "fp32");
   c.rollout_precision = as<std::string>(kv, "rollout_precision", "fp32");
+  c.device_preprocess = as_bool(kv, "device_preprocess", false);
   c.advantage_norm = as_bool(kv, "advantage_norm", false);
   c.seed = as<uint64_t>(kv, "seed", 42);
   return c;
@@ -155,8 +158,13 @@ struct StepOut {
 };
 class SyntheticAtari {
 public:
-  SyntheticAtari(uint64_t seed, size_t max_steps, float max_return, size_t actions)
-      : rng_(seed * 0x9E3779B97F4A7C15ull + 12345), max_steps_(max_steps), max_return_(max_return), actions_(actions) {}
+  // raw = true: the emulator hands over what ALE itself produces - the last TWO 210x160 palette-code frames of the skip
+  // window - and the gray LUT, the 84x84 resize and the 2-frame max (environment.cc:48-55, resize.cc:34-41,
+  // max_and_skip.cc:33-42) run on the device (ALEPPO_FRAMES_RAW_PAIR); raw = false: one finished 84x84 gray frame.
+  SyntheticAtari(uint64_t seed, size_t max_steps, float max_return, size_t actions, bool raw = false)
+      : rng_(seed * 0x9E3779B97F4A7C15ull + 12345), max_steps_(max_steps), max_return_(max_return), actions_(actions),
+        raw_(raw) {}
+  static size_t frame_bytes(bool raw) { return raw ? 2 * 210 * 160 : 84 * 84; }
   // FireReset / EpisodeLife semantics: a full reset only after game over, otherwise continue with the next life
   void reset(uint8_t *frame) {
     if (lives_ == 0) {
@@ -167,6 +175,8 @@ public:
     }
     ball_x_ = 42;
     ball_y_ = 60;
+    prev_x_ = ball_x_;
+    prev_y_ = ball_y_;
     dx_ = (next() & 1) ? 1 : -1;
     dy_ = -1;
     render(frame);
@@ -176,6 +186,8 @@ public:
     paddle_ += (action == 2 ? 3 : action == 3 ? -3 : 0); // NOOP FIRE RIGHT LEFT like Breakout's minimal set
     paddle_ = std::clamp(paddle_, 4, 79);
     for (int k = 0; k < 4; ++k) { // frame_skip emulator frames per agent step
+      prev_x_ = ball_x_;
+      prev_y_ = ball_y_;
       ball_x_ += dx_ * 2;
       ball_y_ += dy_ * 2;
       if (ball_x_ <= 1 || ball_x_ >= 82)
@@ -216,6 +228,25 @@ private:
     return rng_;
   }
   void render(uint8_t *f) const {
+    if (raw_) { // two emulator frames (the ball at its previous and current position), ALE-style even palette codes
+      for (int k = 0; k < 2; ++k) {
+        uint8_t *g = f + (size_t)k * 210 * 160;
+        std::memset(g, 0, 210 * 160);
+        auto rect = [&](int x0, int x1, int y0, int y1, uint8_t c) { // [x0,x1) x [y0,y1) in 84-grid units
+          for (int y = y0 * 210 / 84; y < y1 * 210 / 84; ++y)
+            for (int x = x0 * 160 / 84; x < x1 * 160 / 84; ++x)
+              if (x >= 0 && x < 160 && y >= 0 && y < 210)
+                g[y * 160 + x] = c;
+        };
+        for (int y = 8; y < 20; y += 3)
+          for (int x = 0; x < 84; x += 6)
+            rect(x, x + 6, y, y + 3, (uint8_t)((((x / 6 + y / 3 + bricks_) % 4) * 50 + 60) & ~1));
+        rect(paddle_ - 6, paddle_ + 7, 80, 82, 200);
+        const int bx = k == 0 ? prev_x_ : ball_x_, by = k == 0 ? prev_y_ : ball_y_;
+        rect(bx, bx + 2, by, by + 2, 236);
+      }
+      return;
+    }
     std::memset(f, 0, 84 * 84);
     for (int y = 8; y < 20; ++y)
       for (int x = 0; x < 84; ++x)
@@ -232,7 +263,8 @@ private:
   size_t max_steps_;
   float max_return_;
   size_t actions_;
-  int lives_ = 0, paddle_ = 42, ball_x_ = 42, ball_y_ = 60, dx_ = 1, dy_ = -1, bricks_ = 0;
+  bool raw_;
+  int lives_ = 0, paddle_ = 42, ball_x_ = 42, ball_y_ = 60, prev_x_ = 42, prev_y_ = 60, dx_ = 1, dy_ = -1, bricks_ = 0;
   size_t steps_ = 0;
   float episode_return_ = 0.f;
 };
@@ -732,10 +764,17 @@ int main(int argc, char **argv) {
     // ---- Rollout host half (src/ai/rollout.cc)
     std::vector<SyntheticAtari> envs;
     for (size_t i = 0; i < E; ++i)
-      envs.emplace_back(env0 + i + 0 /*seed arg of train.cc:380*/, cfg.max_steps, cfg.max_return, A);
+      envs.emplace_back(env0 + i + 0 /*seed arg of train.cc:380*/, cfg.max_steps, cfg.max_return, A, cfg.device_preprocess);
     // the workers' frame buffer: page-locked + GPU-mapped, read in place by the ingest kernel (see the file header)
     uint8_t *frames = nullptr;
-    check(ctx, aleppo_host_alloc(ctx, E * 84 * 84, reinterpret_cast<void **>(&frames)));
+    const size_t fbytes = SyntheticAtari::frame_bytes(cfg.device_preprocess); // per environment
+    check(ctx, aleppo_host_alloc(ctx, E * fbytes, reinterpret_cast<void **>(&frames)));
+    if (cfg.device_preprocess) { // ALE's palette -> gray table would go here; the synthetic palette is its own gray value
+      uint8_t lut[256];
+      for (int i = 0; i < 256; ++i)
+        lut[i] = (uint8_t)i;
+      check(ctx, aleppo_set_gray_lut(ctx, lut));
+    }
     std::vector<uint8_t> start_cpu(E, 1), term(E, 0), trunc(E, 0), game_over(E, 0);
     std::vector<float> rewards(E, 0.f), ep_ret(E, 0.f), game_ret(E, 0.f);
     std::vector<size_t> ep_len(E, 0), game_len(E, 0);
@@ -745,13 +784,13 @@ int main(int argc, char **argv) {
     std::cout << "Creating " << cfg.num_workers << " worker threads." << std::endl;
     WorkerPool pool(cfg.num_workers, [&](size_t i) { // Rollout::step (rollout.cc:299-328)
       if (start_cpu[i]) {
-        envs[i].reset(&frames[i * 7056]);
+        envs[i].reset(&frames[i * fbytes]);
         results[i] = StepOut{};
       } else {
         const int64_t a = actions[i];
         if (a < 0 || (size_t)a >= A)
           throw std::out_of_range("Action index out of range for environment " + std::to_string(i));
-        results[i] = envs[i].step((int)a, &frames[i * 7056]);
+        results[i] = envs[i].step((int)a, &frames[i * fbytes]);
       }
     });
     struct Log {
@@ -785,8 +824,8 @@ int main(int argc, char **argv) {
         }
         {
           Profile::Span sp(&prof, "aleppo_step");
-          check(ctx, aleppo_step(ctx, frames, ALEPPO_FRAMES_84, ALEPPO_HOST_MAPPED, rewards.data(), term.data(),
-                                 trunc.data(), start_at_entry.data()));
+          check(ctx, aleppo_step(ctx, frames, cfg.device_preprocess ? ALEPPO_FRAMES_RAW_PAIR : ALEPPO_FRAMES_84,
+                                 ALEPPO_HOST_MAPPED, rewards.data(), term.data(), trunc.data(), start_at_entry.data()));
         }
         for (size_t i = 0; i < E; ++i) { // rollout.cc:239-265
           if (results[i].terminated || results[i].truncated) {
