@@ -120,6 +120,9 @@ def run(args):
         uid = [pkg.Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(uid[0])
+    elif args.force_comm:  # measurement: the data-parallel schedule (early bucket-0 reduce, RCCL calls, no fused tail
+        eng.comm_init(pkg.Engine.comm_unique_id())  # reduce) with a 1-rank communicator - its cost without any peer
+        eng.set_option(pkg.OPT_FORCE_COMM, 1)
     # random-init weights of the reference architecture (orthogonal init is not reproduced; He-uniform fill)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hashfill as hf
@@ -376,7 +379,8 @@ def run(args):
                        "envs_per_gpu": E, "horizon": T, "epochs": epochs, "minibatches": M,
                        "parallelism": f"dp{world}", "frames": "raw u8 [E,2,210,160] pairs resident in HBM",
                        "rollout_planes": "fp16" if args.rollout_fp16 else "fp32",
-                       "update_graph": bool(args.update_graph)},
+                       "update_graph": bool(args.update_graph),
+                       "dp_schedule_forced": bool(args.force_comm and world == 1)},
             "roofline": roofline, "cpu_baseline": cpu, "host_frames": host_legs,
             "vs_reference_published_v1_26289": round(value / 26289.0, 2), "v1_shape": v1,
             "last_loss": float(metrics["loss"][-1, -1]), "last_grad_norm": float(metrics["grad_norm"][-1, -1]),
@@ -499,5 +503,7 @@ if __name__ == "__main__":
                     help="BASELINE configs[4]: half-precision rollout planes (use with --envs 256 --actions 6)")
     ap.add_argument("--update-graph", type=int, default=0,
                     help="1: replay the update loop as a captured hipGraph (the reference's `cuda_graph: true`)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N=1 only: run aleppo_train's data-parallel schedule through a 1-rank RCCL communicator")
     ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py spawns the ranks")
     run(ap.parse_args())

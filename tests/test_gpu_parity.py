@@ -542,6 +542,36 @@ def test_bf16_acting_path_close_to_oracle(pkg):
     eng.close()
 
 
+def test_rccl_path_at_benched_size_with_one_rank_communicator(pkg):
+    """the data-parallel schedule of aleppo_train at the size the multi-GPU bench runs it (B = 4096, H = 512, bf16: slab
+    groups reduced early for bucket 0, bucket all-reduces on the communication stream beside the conv backward, no fused
+    tail reduce) with a 1-rank RCCL communicator: bit-identical to the single-GPU schedule"""
+    E, T, A, H, M = 128, 64, 4, 512, 2
+    N = E * T
+    params = hf.fill_params(2310, H, A)
+    base = hf.hf_bytes(2311, (N // 8, 4, 84, 84))
+    obs = np.concatenate([base ^ np.uint8(11 * k) for k in range(8)])
+    actions = (hf.hf_u32(2312, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(2313, (N, A), -1, 1))
+    adv, ret = hf.hf_range(2314, (N,), -1, 1), hf.hf_range(2315, (N,), -1, 1)
+    masks = (hf.hf_unit(2316, N) >= np.float32(0.05)).astype(np.uint8)
+    out = []
+    for comm in (False, True):
+        eng = pkg.Engine(E, T, A, H, precision=pkg.BF16)
+        if comm:
+            eng.comm_init(pkg.Engine.comm_unique_id())
+            eng.set_option(pkg.OPT_FORCE_COMM, 1)
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 2, M)
+        out.append((m, eng.export_params(), eng.export_grads()))
+        eng.close()
+    for k in ("loss", "grad_norm", "mask_count"):
+        np.testing.assert_array_equal(out[0][0][k], out[1][0][k])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+
+
 @pytest.mark.parametrize("prec", ["bf16"])  # one precision: the 1-rank communicator init alone takes ~60 s
 def test_rccl_path_with_one_rank_communicator(pkg, prec):
     """the data-parallel code path of aleppo_train (mask-count / bucketed gradient / metric all-reduces on the
