@@ -1390,6 +1390,9 @@ extern "C" int aleppo_comm_init(aleppo_ctx *c, const uint8_t id[ALEPPO_UNIQUE_ID
 extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
   CHECK_CTX(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // a captured update holds the kernels the switches selected when it was recorded: any change re-arms the capture
+  c->graph_key = Ctx::GraphKey();
+  c->warm_key = Ctx::GraphKey();
   if (option == ALEPPO_OPT_GENERIC_CONV)
     c->tune.patch_conv = value == 0;
   else if (option == ALEPPO_OPT_FC_PIPE)
