@@ -2,6 +2,7 @@
 // Persistent grids: at most one workgroup per CU (the LDS patch buffers are 41..155 KB), 512 threads.
 #include "common.hpp"
 #include "conv_patch.hpp"
+#include "conv1_wgrad.hpp"
 #include "conv3_tile.hpp"
 #include "conv_fuse.hpp"
 #include <cstdlib>
@@ -143,7 +144,17 @@ template <class L> static int launch_wgrad(hipStream_t s, const WgradParams &P) 
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns) {
   WgradParams P{obs, static_cast<const bf16 *>(dz1), sw, sb, ns, map, 1.0f / 255.0f};
-  return launch_wgrad<LConv1Wgrad>(s, P);
+  static const bool legacy = std::getenv("ALEPPO_C1W_LEGACY") != nullptr; // implicit-GEMM form (A/B)
+  if (legacy)
+    return launch_wgrad<LConv1Wgrad>(s, P);
+  static bool once = false;
+  if (!once) {
+    allow_smem(conv1_wgrad_shift_kernel, c1w::SMEM);
+    once = true;
+  }
+  const int grid = (int)std::min<long>(2 * ns, std::min(num_cus(), MAXS_C1));
+  hipLaunchKernelGGL(conv1_wgrad_shift_kernel, dim3(grid), dim3(c1w::NTHREADS), c1w::SMEM, s, P);
+  return grid;
 }
 // conv2 dgrad + conv1 wgrad in one launch (conv_fuse.hpp); returns the number of slabs written
 int patch_conv2_dgrad_conv1_wgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, const uint32_t *obs,

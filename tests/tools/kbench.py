@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(_T))
 import hashfill as hf
 from __graft_entry__ import load_package
 pkg = load_package()
-E, T, A, H, M = 128, 128, int(os.environ.get("KB_A", "4")), 512, 4
+E, T, A, H, M = 128, 128, int(os.environ.get("KB_A", "4")), 512, int(os.environ.get("KB_M", "4"))
 prec = pkg.FP32 if os.environ.get("KB_FP32") else pkg.BF16
 eng = pkg.Engine(E, T, A, H, precision=prec, max_minibatch=E * T // M)
 eng.load_params(hf.fill_params(310, H, A))
