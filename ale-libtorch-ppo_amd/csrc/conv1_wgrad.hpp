@@ -71,7 +71,11 @@ __global__ __launch_bounds__(c1w::NTHREADS) void conv1_wgrad_shift_kernel(WgradP
       u32x4 x[NXV], d[NDV];
     };
     Regs R0, R1, R2, R3;
-    // unconditional, clamped loads: hipcc then counts what is outstanding and waits for ONE set (conv_patch.hpp)
+    // unconditional, clamped loads: hipcc then counts what is outstanding and waits for ONE set (conv_patch.hpp).
+    // Non-temporal: this kernel runs beside the slab reduce of the other stream, and with ordinary loads its 220 MB
+    // stream pushes the slabs the reduce is about to read out of L2 / the memory-side cache (same box: conv1 wgrad 88 ->
+    // 74 us, the reduce 58 -> 46 us, update 7.70 -> 7.50 ms).  The hint is not a general win: on the operands of the other
+    // conv kernels - cold or warm - it measured 3-8 us SLOWER per kernel (update 7.57-7.70 ms) and stays off there.
     auto gload = [&](Regs &R, long g) {
       g = min(g, ngroups - 1);
       const uint32_t n = (uint32_t)(g >> 1) + (uint32_t)P.map.n0, tp = (uint32_t)P.map.TP;
@@ -81,10 +85,10 @@ __global__ __launch_bounds__(c1w::NTHREADS) void conv1_wgrad_shift_kernel(WgradP
       const u32x4 *pd = reinterpret_cast<const u32x4 *>(P.dy + g * (long)(200 * 32));
 #pragma unroll
       for (int i = 0; i < NXV; ++i)
-        R.x[i] = px[min(tid + NPROD * i, XV - 1)];
+        R.x[i] = __builtin_nontemporal_load(px + min(tid + NPROD * i, XV - 1));
 #pragma unroll
       for (int i = 0; i < NDV; ++i)
-        R.d[i] = pd[min(tid + NPROD * i, DV - 1)];
+        R.d[i] = __builtin_nontemporal_load(pd + min(tid + NPROD * i, DV - 1));
     };
     auto swrite = [&](Regs &R, int buf) {
       bf16 *dx = sbuf + (size_t)buf * BUF_ELEMS, *dd = dx + X_ELEMS;

@@ -12,7 +12,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 CLASS = [("conv3_dgrad_tile_kernel", "conv3_dgrad"), ("LConv1Fwd", "conv1_fwd"), ("LConv2Fwd", "conv2_fwd"), ("LConv3Fwd", "conv3_fwd"), ("LConv3Dgrad", "conv3_dgrad"),
-         ("LConv2Dgrad", "conv2_dgrad"), ("LConv1Wgrad", "conv1_wgrad"), ("LConv2Wgrad", "conv2_wgrad"),
+         ("LConv2Dgrad", "conv2_dgrad"), ("conv1_wgrad_shift_kernel", "conv1_wgrad"), ("LConv1Wgrad", "conv1_wgrad"), ("LConv2Wgrad", "conv2_wgrad"),
          ("LConv3Wgrad", "conv3_wgrad"), ("gemm_pipe_kernel<0", "fc_fwd"), ("gemm_pipe_kernelILi0", "fc_fwd"),
          ("gemm_pipe_kernel<1", "fc_dgrad"), ("gemm_pipe_kernelILi1", "fc_dgrad"), ("gemm_pipe_kernel<2", "fc_wgrad"),
          ("gemm_pipe_kernelILi2", "fc_wgrad"), ("gemm_tn_kernel", "fc_wgrad"), ("head_train_kernel", "head"),
