@@ -319,6 +319,39 @@ def test_bf16_patch_kernels_match_generic_kernels(pkg, N):
     np.testing.assert_allclose(g0 / c0, w["last_grads"] / cw, atol=3e-2 * np.abs(w["last_grads"] / cw).max())
 
 
+@pytest.mark.parametrize("N,M", [(8, 2), (8, 1), (24, 2), (264, 1), (520, 1), (1032, 1), (3080, 1)])
+def test_bf16_conv1_weight_gradient_ragged_sizes(pkg, N, M):
+    """conv1's weight / bias gradient from the tap-shift kernel (csrc/conv1_wgrad.hpp: half-sample groups dealt to
+    <= 256 workgroups, four groups in flight, consumers skip groups past the end) against the generic gather-GEMM on the
+    same bf16 operands, per tensor, at minibatch sizes that exercise every tail: fewer groups than workgroups (4, 8, 12
+    samples), one group more than the workgroups (264 samples -> 528 groups: 2 or 3 per workgroup), group counts of
+    4k + 1 .. 4k + 3 per workgroup (520, 1032, 3080 samples)."""
+    H, A = 512, 4
+    params = hf.fill_params(1210, H, A)
+    obs = hf.hf_bytes(1211, (N, 4, 84, 84))
+    actions = (hf.hf_u32(1212, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(1213, (N, A), -1, 1))
+    adv, ret = hf.hf_range(1214, (N,), -1, 1), hf.hf_range(1215, (N,), -1, 1)
+    masks = np.ones(N, np.uint8)
+    offs = orc.param_offsets(H, A)
+    res = {}
+    for generic in (1, 0):
+        eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
+        eng.set_generic_conv(generic)
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 1, M)
+        res[generic] = (eng.export_grads(), m["grad_norm"])
+        eng.close()
+    (g1, n1), (g0, n0) = res[1], res[0]
+    np.testing.assert_allclose(n0, n1, rtol=5e-3)
+    for k, name in ((0, "conv1.w"), (1, "conv1.b")):
+        a, b = g0[offs[k]:offs[k + 1]], g1[offs[k]:offs[k + 1]]
+        rel = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+        # same bf16 operands, different fp32 summation order (and bf16 dz1 produced by different conv2 dgrad kernels)
+        assert rel <= 1e-2, f"{name}: relative L2 {rel:.3e} at N={N}, M={M}"
+
+
 @pytest.mark.parametrize("N,M,H", [(1400, 2, 512), (2048, 2, 512), (4096, 1, 512), (1400, 2, 256), (1024, 1, 320)])
 def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M, H):
     """minibatches > 256 samples route the bf16 fc forward / dgrad through the pipelined LDS-DMA GEMM
