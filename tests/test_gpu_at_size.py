@@ -378,6 +378,58 @@ def test_captured_update_graph_is_bit_identical_to_eager(pkg, prec):
     assert np.abs(eager[0][3][2] - eager[0][2][2]).max() > 0  # the replays kept learning
 
 
+def test_engines_trained_concurrently_from_threads_match_engines_trained_alone(pkg):
+    """Two contexts in one process, each driven by its own host thread at the same time (different kernel switches,
+    different precisions): every context carries its own streams, scratch, switches and error state, every entry point
+    selects its device and its context's switches, so the results must be bit-identical to the same engines run one after
+    the other (rollout.h keeps everything per Rollout object; ADVICE r1: process-global switches)."""
+    import threading
+    cfgs = [dict(E=64, T=32, A=4, H=512, prec=pkg.BF16, generic=0, seed=2310),
+            dict(E=16, T=8, A=6, H=64, prec=pkg.FP32, generic=0, seed=2320),
+            dict(E=64, T=32, A=6, H=512, prec=pkg.BF16, generic=1, seed=2330)]
+
+    def build(c):
+        N = c["E"] * c["T"]
+        eng = pkg.Engine(c["E"], c["T"], c["A"], c["H"], precision=c["prec"])
+        eng.set_generic_conv(c["generic"])
+        eng.load_params(hf.fill_params(c["seed"], c["H"], c["A"]))
+        eng.set_batch(hf.hf_bytes(c["seed"] + 1, (N, 4, 84, 84)), (hf.hf_u32(c["seed"] + 2, N) % np.uint32(c["A"])).astype(np.int64),
+                      orc.log_softmax(hf.hf_range(c["seed"] + 3, (N, c["A"]), -1, 1)), hf.hf_range(c["seed"] + 4, (N,), -1, 1),
+                      hf.hf_range(c["seed"] + 5, (N,), -1, 1), np.ones(N, np.uint8))
+        return eng
+
+    def work(eng, out, k):
+        try:
+            hist = []
+            for call in range(3):
+                m = eng.train(2.5e-4, 2, 2)
+                hist.append((m["loss"].copy(), m["grad_norm"].copy()))
+            out[k] = (hist, eng.export_params())
+        except Exception as e:  # surfaced by the asserts below
+            out[k] = e
+
+    alone, together = {}, {}
+    for k, c in enumerate(cfgs):
+        eng = build(c)
+        work(eng, alone, k)
+        eng.close()
+    engs = [build(c) for c in cfgs]
+    threads = [threading.Thread(target=work, args=(e, together, k)) for k, e in enumerate(engs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in engs:
+        e.close()
+    for k in range(len(cfgs)):
+        assert not isinstance(alone[k], Exception), alone[k]
+        assert not isinstance(together[k], Exception), together[k]
+        for (l0, g0), (l1, g1) in zip(alone[k][0], together[k][0]):
+            np.testing.assert_array_equal(l0, l1, err_msg=f"engine {k}: loss")
+            np.testing.assert_array_equal(g0, g1, err_msg=f"engine {k}: grad norm")
+        np.testing.assert_array_equal(alone[k][1], together[k][1], err_msg=f"engine {k}: parameters")
+
+
 # ------------------------------------------------------------------ advantage normalisation (extension; unpinned)
 @pytest.mark.parametrize("E,T", [(6, 9), (128, 32)])
 def test_advantage_norm_extension_vs_oracle(pkg, E, T):
