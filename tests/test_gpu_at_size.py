@@ -430,6 +430,53 @@ def test_engines_trained_concurrently_from_threads_match_engines_trained_alone(p
         np.testing.assert_array_equal(alone[k][1], together[k][1], err_msg=f"engine {k}: parameters")
 
 
+def test_rollouts_run_concurrently_from_threads_match_rollouts_run_alone(pkg):
+    """the acting path of two contexts at the same time (own pinned action buffer, ticket word and device counter each):
+    every stored plane equals the same rollout run alone"""
+    import threading
+    cfgs = [dict(E=40, T=12, A=4, H=512, prec=pkg.BF16, seed=2410), dict(E=9, T=20, A=6, H=64, prec=pkg.FP32, seed=2420)]
+    keys = ("observations", "actions", "values", "logits", "advantages", "returns", "masks")
+
+    def build(c):
+        E, T = c["E"], c["T"]
+        dev = DeviceBytes(hf.hf_bytes(c["seed"] + 1, (T, E, 84, 84)))
+        te, tr, st = _flags(c["seed"] + 2, T, E)
+        eng = pkg.Engine(E, T, c["A"], c["H"], precision=c["prec"], seed=c["seed"])
+        eng.load_params(hf.fill_params(c["seed"], c["H"], c["A"]))
+        return eng, dev, (hf.hf_range(c["seed"] + 3, (T, E), -2, 2), te, tr, st)
+
+    def work(item, out, k):
+        eng, dev, (rew, te, tr, st) = item
+        try:
+            for _ in range(2):  # two rollouts: the second starts from the first one's last stack
+                eng.replay_rollout(dev.addr, pkg.FRAMES_84, eng.E * 7056, rew, te, tr, st)
+                eng.finish_rollout()
+            out[k] = {q: eng.read_batch(q) for q in keys}
+        except Exception as e:
+            out[k] = e
+
+    alone, together = {}, {}
+    for k, c in enumerate(cfgs):
+        item = build(c)
+        work(item, alone, k)
+        item[0].close()
+        item[1].free()
+    items = [build(c) for c in cfgs]
+    threads = [threading.Thread(target=work, args=(it, together, k)) for k, it in enumerate(items)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for it in items:
+        it[0].close()
+        it[1].free()
+    for k in range(len(cfgs)):
+        assert not isinstance(alone[k], Exception), alone[k]
+        assert not isinstance(together[k], Exception), together[k]
+        for q in keys:
+            np.testing.assert_array_equal(alone[k][q], together[k][q], err_msg=f"engine {k}: {q}")
+
+
 # ------------------------------------------------------------------ advantage normalisation (extension; unpinned)
 @pytest.mark.parametrize("E,T", [(6, 9), (128, 32)])
 def test_advantage_norm_extension_vs_oracle(pkg, E, T):
