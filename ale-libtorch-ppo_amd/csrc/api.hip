@@ -345,7 +345,7 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(dalloc(&c->lut, 256));
   CK(dalloc(&c->d_start, (size_t)E));
   CK(dalloc(&c->d_frames, (size_t)E * 2 * RAW_H * RAW_W));
-  CK(dalloc(&c->d_noise, (size_t)E * A * 4));
+  CK(dalloc(&c->d_noise, (size_t)2 * E * A * 4));
   CK(dalloc(&c->d_err, 16));
   CK(dalloc(&c->d_done, 16));
   {
@@ -359,7 +359,9 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_rec), c->step_rec_bytes * T, hipHostMallocDefault));
   std::memset(c->h_rec, 0, c->step_rec_bytes * T);
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_frames), (size_t)E * 2 * RAW_H * RAW_W, hipHostMallocDefault));
-  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_noise), (size_t)E * A * 4, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_noise), (size_t)2 * E * A * 4, hipHostMallocDefault));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_go), 64, hipHostMallocMapped));
+  std::memset(c->h_go, 0, 64);
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), 16, hipHostMallocDefault));
   std::memset(c->h_actions, 0, (size_t)(E + 8) * 8);
   CK(dalloc(reinterpret_cast<char **>(&c->adv_n), (size_t)c->N * c->rsz));
@@ -434,7 +436,7 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
       hipFree(p);
   if (c->Pc && c->Pc != c->P)
     hipFree(c->Pc);
-  void *host[] = {c->h_actions, c->h_step, c->h_rec, c->h_frames, c->h_noise, c->h_err, c->h_metric_red,
+  void *host[] = {c->h_go, c->h_actions, c->h_step, c->h_rec, c->h_frames, c->h_noise, c->h_err, c->h_metric_red,
                   c->h_adam_sched};
   for (void *p : host)
     if (p)
@@ -564,10 +566,12 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, void *logits_dst,
   }
   c->pre_acted = -1; // (consumed; a3 / hpart are scratch again)
   const float *dn = nullptr;
-  if (noise) {
-    std::memcpy(c->h_noise, noise, (size_t)c->E * c->A * 4);
-    HIPCHK(c, hipMemcpyAsync(c->d_noise, c->h_noise, (size_t)c->E * c->A * 4, hipMemcpyHostToDevice, c->stream));
-    dn = c->d_noise;
+  if (noise) { // (two staging halves: with a gated replay the next slot is enqueued before this copy has run)
+    const size_t half = (size_t)(c->noise_flip++ & 1u) * c->E * c->A;
+    std::memcpy(c->h_noise + half, noise, (size_t)c->E * c->A * 4);
+    HIPCHK(c, hipMemcpyAsync(c->d_noise + half, c->h_noise + half, (size_t)c->E * c->A * 4, hipMemcpyHostToDevice,
+                             c->stream));
+    dn = c->d_noise + half;
   }
   int64_t *pinned_dev = nullptr;
   HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&pinned_dev), c->h_actions, 0));
@@ -584,8 +588,8 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, void *logits_dst,
   return ALEPPO_OK;
 }
 
-extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **actions_pinned) {
-  CHECK_CTX(c);
+// enqueue slot c->t's acting kernels (whatever aleppo_step has not already run) + the head that publishes the actions
+static int act_enqueue(aleppo_ctx *c, const float *noise) {
   if (c->t >= c->T)
     return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
   if (c->t == 0 && c->need_carry) { // slot T of the previous rollout is this rollout's first observation
@@ -593,25 +597,34 @@ extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **act
     c->need_carry = false;
   }
   const size_t o = (size_t)c->t * c->E;
-  int rc = do_act(c, noise, c->t, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
+  return do_act(c, noise, c->t, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
+}
+// wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
+static int act_wait(aleppo_ctx *c, long long ticket) {
+  volatile long long *tk = reinterpret_cast<volatile long long *>(c->h_actions + c->E);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  if (c->dbg_no_publish)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  while (!c->dbg_no_publish && *tk != ticket) {
+    __builtin_ia32_pause();
+    if ((++spins & 1023u) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **actions_pinned) {
+  CHECK_CTX(c);
+  int rc = act_enqueue(c, noise);
   if (rc)
     return rc;
-  { // wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
-    volatile long long *tk = reinterpret_cast<volatile long long *>(c->h_actions + c->E);
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    if (c->dbg_no_publish)
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-    while (!c->dbg_no_publish && *tk != c->ticket) {
-      __builtin_ia32_pause();
-      if ((++spins & 1023u) == 0 &&
-          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        break;
-      }
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
+  rc = act_wait(c, c->ticket);
+  if (rc)
+    return rc;
   if (actions_pinned)
     *actions_pinned = c->h_actions;
   return ALEPPO_OK;
@@ -769,14 +782,58 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
   if (c->t != 0)
     return set_err(c, ALEPPO_ERR_RUNTIME, "replay_rollout needs an empty rollout buffer");
   const size_t E = (size_t)c->E;
-  for (int t = 0; t < c->T; ++t) { // rollout.cc:198-278 with the emulator replaced by the recorded trace
-    int rc = aleppo_act(c, noise ? noise + (size_t)t * E * c->A : nullptr, nullptr);
-    if (rc)
-      return rc;
+  // rollout.cc:198-278 with the emulator replaced by the recorded trace.  The stream runs ONE slot ahead of the host:
+  // slot t + 1's kernels (ingest of the frames the emulator produces from action t, convolutions, fc, head) are enqueued
+  // while slot t is still on the GPU, behind a hipStreamWaitValue32 on a pinned word that the host writes once it HAS
+  // slot t's actions (and, with a live emulator, the frames).  The hand-off keeps its order - the GPU never touches slot
+  // t + 1's frames before the host has seen action t - but the next slot starts ~1 us after the host's store instead of
+  // a kernel-launch latency after it (micro-benchmark tests/tools/waitvalue.hip: 3.7 vs 6.7 us per ping-pong).
+  static const bool gated_env = [] {
+    const char *e = getenv("ALEPPO_REPLAY_GATED");
+    return !e || atoi(e) != 0;
+  }();
+  const bool gated = gated_env && !c->prof_on && !c->dbg_no_publish;
+  auto noise_at = [&](int t) { return noise ? noise + (size_t)t * E * c->A : nullptr; };
+  auto release_all = [&]() { // (error paths: never leave the stream parked on the flag)
+    __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
+  };
+  int rc = act_enqueue(c, noise_at(0));
+  if (rc)
+    return rc;
+  for (int t = 0; t < c->T; ++t) {
+    const long long ticket_t = c->ticket; // of act(t), enqueued above / in the previous iteration
+    if (gated) {
+      uint32_t *go_dev = nullptr;
+      HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&go_dev), c->h_go, 0));
+      c->go_seq++;
+      const hipError_t e = hipStreamWaitValue32(c->stream, go_dev, c->go_seq, hipStreamWaitValueGte, 0xFFFFFFFFu);
+      if (e != hipSuccess) {
+        c->go_seq--;
+        release_all();
+        HIPCHK(c, e);
+      }
+    } else {
+      rc = act_wait(c, ticket_t);
+      if (rc)
+        return rc;
+    }
     rc = aleppo_step(c, frames + (size_t)t * slot_stride_bytes, kind, location, rewards + (size_t)t * E,
                      terminated + (size_t)t * E, truncated + (size_t)t * E, episode_start + (size_t)t * E);
-    if (rc)
+    if (rc == ALEPPO_OK && t + 1 < c->T)
+      rc = act_enqueue(c, noise_at(t + 1));
+    if (gated) {
+      if (rc) {
+        release_all();
+        hipStreamSynchronize(c->stream);
+        return rc;
+      }
+      rc = act_wait(c, ticket_t); // the host has slot t's actions: the emulator would step now
+      release_all();              // ... and hand over slot t + 1's frames
+      if (rc)
+        return rc;
+    } else if (rc) {
       return rc;
+    }
   }
   return ALEPPO_OK;
 }

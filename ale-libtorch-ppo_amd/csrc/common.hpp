@@ -98,10 +98,13 @@ struct Ctx {
   uint8_t *lut = nullptr;      // [256]
   uint8_t *d_start = nullptr;  // [E] episode-start flags of the slot being ingested
   uint8_t *d_frames = nullptr; // staging for host frames (max(E*2*210*160))
-  float *d_noise = nullptr;    // [E][A]
+  float *d_noise = nullptr;    // [2][E][A] (two staging halves: a slot may be enqueued while the previous one is pending)
   int *d_err = nullptr;        // device error word (flag overlap)
   unsigned int *d_done = nullptr; // arrival counter of the head kernel's ticket publish
   long long ticket = 0;        // last ticket published to h_actions[E]
+  uint32_t *h_go = nullptr;    // pinned, GPU-visible: the stream waits on it (hipStreamWaitValue32) before a gated slot
+  uint32_t go_seq = 0;         // last value the stream was told to wait for / the host released
+  unsigned noise_flip = 0;
   // pinned host staging
   int64_t *h_actions = nullptr; // [E]
   uint8_t *h_step = nullptr;    // one step record (aleppo_record_step path)

@@ -262,7 +262,12 @@ def run(args):
             table[k] = dict(ms=round(ms, 4), TFLOPs=round(tf, 1), GBps=round(gbs, 1),
                             bound="hbm" if t_hbm >= t_mfma else "mfma",
                             frac=round(max(t_hbm, t_mfma) / (ms * 1e-3), 4))
-        dom = max(table, key=lambda k: trn[k][0] * trn[k][1])
+        # dominant kernel = the longest one on the update's CRITICAL PATH (main stream: forward chain, dgrad chain, conv1
+        # wgrad).  The weight-gradient kernels of the second stream run in the main stream's shadow and stretch with it
+        # (fc wgrad: 38 us alone, 72 us beside fc dgrad + conv3 dgrad): their timed-region durations are not a cost.
+        main_stream = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv2_dgrad", "conv1_wgrad",
+                       "conv2d_conv1w")
+        dom = max((k for k in table if k in main_stream), key=lambda k: trn[k][0] * trn[k][1])
         d = table[dom]
         # HBM traffic of the dominant kernel: recorded by `tests/tools/pmc_traffic.py` (rocprofv3 --pmc passes cannot run
         # inside this process).  The record carries the hash of the kernel sources it was measured on; a record from

@@ -1,0 +1,58 @@
+// Micro-benchmark: host <-> GPU ping-pong per "slot", two ways.
+//  (a) launch per slot: host polls a ticket written by the slot's kernel, then launches the next slot's kernel;
+//  (b) pre-enqueued: every slot's kernel is queued up front behind hipStreamWaitValue32 on a host-written flag; the host
+//      polls the ticket and writes the next flag.
+// hipcc --offload-arch=gfx950 -O3 tests/tools/waitvalue.hip -o build_tools/waitvalue
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+__global__ void slot_kernel(volatile unsigned int *ticket, unsigned int t) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    __hip_atomic_store(const_cast<unsigned int *>(ticket), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int main() {
+  const int T = 2000;
+  unsigned int *ticket, *flag;
+  CK(hipHostMalloc(reinterpret_cast<void **>(&ticket), 64, hipHostMallocMapped));
+  CK(hipHostMalloc(reinterpret_cast<void **>(&flag), 64, hipHostMallocMapped));
+  hipStream_t s;
+  CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  volatile unsigned int *vt = ticket;
+  for (int rep = 0; rep < 2; ++rep) {
+    *vt = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int t = 1; t <= (unsigned)T; ++t) {
+      hipLaunchKernelGGL(slot_kernel, dim3(1), dim3(64), 0, s, ticket, t);
+      while (*vt != t) {
+      }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    std::printf("(a) launch per slot:        %.2f us per slot\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / T);
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    *vt = 0;
+    *reinterpret_cast<volatile unsigned int *>(flag) = 0;
+    for (unsigned int t = 1; t <= (unsigned)T; ++t) {
+      hipError_t e = hipStreamWaitValue32(s, flag, t, hipStreamWaitValueGte, 0xFFFFFFFFu);
+      if (e != hipSuccess) {
+        std::printf("hipStreamWaitValue32: %s\n", hipGetErrorString(e));
+        return 0;
+      }
+      hipLaunchKernelGGL(slot_kernel, dim3(1), dim3(64), 0, s, ticket, t);
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int t = 1; t <= (unsigned)T; ++t) {
+      __atomic_store_n(flag, t, __ATOMIC_RELEASE);
+      while (*vt != t) {
+      }
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    CK(hipStreamSynchronize(s));
+    std::printf("(b) pre-enqueued wait-value: %.2f us per slot\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / T);
+  }
+  return 0;
+}
