@@ -55,7 +55,7 @@ EXPORTS = [
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
     "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option", "aleppo_export_optimizer",
     "aleppo_import_optimizer", "aleppo_replay_rollout", "aleppo_get_option",
-    "aleppo_host_alloc", "aleppo_host_free",
+    "aleppo_host_alloc", "aleppo_host_free", "aleppo_arm_step", "aleppo_release_step",
 ]
 
 
@@ -322,6 +322,16 @@ class Engine:
         loc = DEVICE if device_ptr is not None else HOST
         self._c(lib().aleppo_step(self._ctx, fr, kind, loc, _ptr(_f32(rewards)), _ptr(_u8(terminated)),
                                   _ptr(_u8(truncated)), _ptr(_u8(episode_start))))
+
+    def arm_step(self, frames_addr, start_addr, kind=FRAMES_84, noise_next=None):
+        """aleppo_arm_step: enqueue the next step (frames / episode-start bytes at mapped host addresses the emulators are
+        about to fill) and the next slot's acting kernels behind the release word"""
+        n = None if noise_next is None else _f32(noise_next)
+        self._c(lib().aleppo_arm_step(self._ctx, C.c_void_p(frames_addr), kind, C.c_void_p(start_addr), _ptr(n)))
+
+    def release_step(self, rewards, terminated, truncated):
+        """aleppo_release_step: the emulators are done - release the stream, record the slot's scalars"""
+        self._c(lib().aleppo_release_step(self._ctx, _ptr(_f32(rewards)), _ptr(_u8(terminated)), _ptr(_u8(truncated))))
 
     # -- low-overhead variants for tight host loops: raw addresses, no numpy conversions --
     def act_fast(self):

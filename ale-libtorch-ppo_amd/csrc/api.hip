@@ -417,6 +417,8 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
     return;
   set_tuning(nullptr);
   (void)hipSetDevice(c->cfg.device_ordinal);
+  if (c->armed && c->h_go) // an armed step parks the stream on the release word: let it go before waiting for the device
+    __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
   hipDeviceSynchronize();
   if (c->graph_exec)
     hipGraphExecDestroy(c->graph_exec);
@@ -589,15 +591,15 @@ static int do_act(aleppo_ctx *c, const float *noise, int slot, void *logits_dst,
 }
 
 // enqueue slot c->t's acting kernels (whatever aleppo_step has not already run) + the head that publishes the actions
-static int act_enqueue(aleppo_ctx *c, const float *noise) {
-  if (c->t >= c->T)
+static int act_enqueue(aleppo_ctx *c, const float *noise, int slot) {
+  if (slot >= c->T)
     return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
-  if (c->t == 0 && c->need_carry) { // slot T of the previous rollout is this rollout's first observation
+  if (slot == 0 && c->need_carry) { // slot T of the previous rollout is this rollout's first observation
     launch_copy_slot(c->stream, c->obs, c->E, c->T + 1, c->T, 0);
     c->need_carry = false;
   }
-  const size_t o = (size_t)c->t * c->E;
-  return do_act(c, noise, c->t, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
+  const size_t o = (size_t)slot * c->E;
+  return do_act(c, noise, slot, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
 }
 // wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
 static int act_wait(aleppo_ctx *c, long long ticket) {
@@ -617,12 +619,23 @@ static int act_wait(aleppo_ctx *c, long long ticket) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return ALEPPO_OK;
 }
+#define CHECK_NOT_ARMED(c)                                                                                             \
+  do {                                                                                                                 \
+    if ((c)->armed)                                                                                                    \
+      return set_err(c, ALEPPO_ERR_RUNTIME, "a step is armed: call aleppo_release_step first");                        \
+  } while (0)
 extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **actions_pinned) {
   CHECK_CTX(c);
-  int rc = act_enqueue(c, noise);
-  if (rc)
-    return rc;
-  rc = act_wait(c, c->ticket);
+  CHECK_NOT_ARMED(c);
+  int rc = ALEPPO_OK;
+  if (c->act_queued_slot == c->t && c->t < c->T) { // enqueued by aleppo_arm_step (with ITS noise): only the wait is left
+    c->act_queued_slot = -1;
+    rc = act_wait(c, c->act_queued_ticket);
+  } else {
+    rc = act_enqueue(c, noise, c->t);
+    if (rc == ALEPPO_OK)
+      rc = act_wait(c, c->ticket);
+  }
   if (rc)
     return rc;
   if (actions_pinned)
@@ -696,9 +709,52 @@ static int do_record(aleppo_ctx *c, const float *rewards, const uint8_t *termina
   return ALEPPO_OK;
 }
 
+// the GPU side of a step: slot t's new frames -> observation slot t + 1 (+ its convolutions and fc where fused).  The
+// episode-start flags come as a kernel-argument bitmask (sb) or, for a step enqueued before the emulator has produced
+// them (aleppo_arm_step), as bytes in mapped host memory (start_mapped: host pointer, start_dev: its device address).
+static int step_enqueue(aleppo_ctx *c, const uint8_t *df, int kind, int location, const StartBits *sb,
+                        const uint8_t *start_mapped, int t) {
+  const int E = c->E;
+  uint8_t *start_dev = nullptr;
+  if (start_mapped)
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&start_dev), const_cast<uint8_t *>(start_mapped), 0));
+  // Fused ingest pays for given 84x84 frames (15.7 -> 14.4 ms per 128-slot rollout+update with the frames in mapped host
+  // memory) and for raw pairs read over the bus (one environment's pair is staged by ONE workgroup with nine 16-byte
+  // loads per thread in flight).  Raw pairs resident in HBM stay on the stand-alone ingest kernel: there the palette
+  // lookups of 67 K source bytes per environment are spread over all 256 CUs instead of the 128 acting workgroups
+  // (measured: 5.01 vs 5.10 ms per rollout).
+  const bool fuse = c->prec == ALEPPO_BF16 && use_patch_kernels() && c->tune.fused_act &&
+                    !(kind == ALEPPO_FRAMES_RAW_PAIR && location != ALEPPO_HOST_MAPPED && c->tune.fused_act < 2);
+  if (fuse) {
+    // ONE launch forms slot t+1's stack from the new frames AND runs conv1 -> conv2 -> conv3 on it, then the split-K fc:
+    // when the next aleppo_act (or aleppo_finish_rollout's bootstrap) arrives only the head + sampling kernel is left.
+    // A slot's critical path is 3 dependent launches instead of 4 and the stack skips one HBM round trip.
+    const SampleMap map = slot_map(c, t + 1);
+    prof_begin(c, ALEPPO_K_ACT_FUSED);
+    patch_act_convs(c->stream, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), Pcw(c, P_W2), Pf(c, P_B2), Pcw(c, P_W3),
+                    Pf(c, P_B3), c->a3, E, kind == ALEPPO_FRAMES_RAW_PAIR ? 2 : 1, df, c->lut, sb, -(long)FRAME_PIX,
+                    start_dev);
+    prof_end(c, ALEPPO_K_ACT_FUSED);
+    prof_begin(c, ALEPPO_K_FC_FWD);
+    fc_fwd_splitk(c->stream, c->prec, c->a3, Pcw(c, P_WFC), c->hpart, E, c->H);
+    prof_end(c, ALEPPO_K_FC_FWD);
+    c->pre_acted = t + 1;
+  } else {
+    if (start_mapped) // (every thread of the stand-alone kernel reads its flag: from HBM, not across the bus)
+      HIPCHK(c, hipMemcpyAsync(c->d_start, start_mapped, E, hipMemcpyHostToDevice, c->stream));
+    prof_begin(c, ALEPPO_K_INGEST);
+    launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, start_mapped ? c->d_start : nullptr, sb, c->obs, E,
+                  c->T + 1, t, t + 1);
+    prof_end(c, ALEPPO_K_INGEST);
+    c->pre_acted = -1;
+  }
+  return ALEPPO_OK;
+}
+
 extern "C" int aleppo_push_frames(aleppo_ctx *c, const uint8_t *frames, int kind, int location,
                                   const uint8_t *episode_start) {
   CHECK_CTX(c);
+  CHECK_NOT_ARMED(c);
   int rc = do_push(c, frames, kind, location, episode_start);
   if (rc == ALEPPO_OK)
     HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
@@ -713,6 +769,7 @@ extern "C" int aleppo_record_step(aleppo_ctx *c, const float *rewards, const uin
 extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int location, const float *rewards,
                            const uint8_t *terminated, const uint8_t *truncated, const uint8_t *episode_start) {
   CHECK_CTX(c);
+  CHECK_NOT_ARMED(c);
   if (!frames || !rewards || !terminated || !truncated || !episode_start)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
   if (kind != ALEPPO_FRAMES_84 && kind != ALEPPO_FRAMES_RAW_PAIR)
@@ -738,36 +795,77 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
   int rc = upload_frames(c, frames, kind, location, &df);
   if (rc)
     return rc;
-  // Fused ingest pays for given 84x84 frames (15.7 -> 14.4 ms per 128-slot rollout+update with the frames in mapped host
-  // memory) and for raw pairs read over the bus (one environment's pair is staged by ONE workgroup with nine 16-byte
-  // loads per thread in flight).  Raw pairs resident in HBM stay on the stand-alone ingest kernel: there the palette
-  // lookups of 67 K source bytes per environment are spread over all 256 CUs instead of the 128 acting workgroups
-  // (measured: 5.01 vs 5.10 ms per rollout).
-  const bool fuse = c->prec == ALEPPO_BF16 && use_patch_kernels() && c->tune.fused_act &&
-                    !(kind == ALEPPO_FRAMES_RAW_PAIR && location != ALEPPO_HOST_MAPPED && c->tune.fused_act < 2);
-  if (fuse) {
-    // ONE launch forms slot t+1's stack from the new frames AND runs conv1 -> conv2 -> conv3 on it, then the split-K fc:
-    // when the next aleppo_act (or aleppo_finish_rollout's bootstrap) arrives only the head + sampling kernel is left.
-    // A slot's critical path is 3 dependent launches instead of 4 and the stack skips one HBM round trip.
-    const SampleMap map = slot_map(c, c->t + 1);
-    prof_begin(c, ALEPPO_K_ACT_FUSED);
-    patch_act_convs(c->stream, c->obs, map, Pcw(c, P_W1), Pf(c, P_B1), Pcw(c, P_W2), Pf(c, P_B2), Pcw(c, P_W3),
-                    Pf(c, P_B3), c->a3, E, kind == ALEPPO_FRAMES_RAW_PAIR ? 2 : 1, df, c->lut, &sb, -(long)FRAME_PIX);
-    prof_end(c, ALEPPO_K_ACT_FUSED);
-    prof_begin(c, ALEPPO_K_FC_FWD);
-    fc_fwd_splitk(c->stream, c->prec, c->a3, Pcw(c, P_WFC), c->hpart, E, c->H);
-    prof_end(c, ALEPPO_K_FC_FWD);
-    c->pre_acted = c->t + 1;
-  } else {
-    prof_begin(c, ALEPPO_K_INGEST);
-    launch_ingest(c->stream, kind == ALEPPO_FRAMES_RAW_PAIR, df, c->lut, nullptr, &sb, c->obs, E, c->T + 1, c->t,
-                  c->t + 1);
-    prof_end(c, ALEPPO_K_INGEST);
-    c->pre_acted = -1;
-  }
+  rc = step_enqueue(c, df, kind, location, &sb, nullptr, c->t);
+  if (rc)
+    return rc;
   HIPCHK(c, hipGetLastError());
   if (location == ALEPPO_HOST)
     HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
+  c->t++;
+  return ALEPPO_OK;
+}
+// Live loops one slot ahead (the replay loop below does the same with a recorded trace): see include/aleppo.h.
+extern "C" int aleppo_arm_step(aleppo_ctx *c, const uint8_t *frames, int kind, const uint8_t *episode_start_mapped,
+                               const float *noise_next) {
+  CHECK_CTX(c);
+  CHECK_NOT_ARMED(c);
+  if (!frames || !episode_start_mapped)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (kind != ALEPPO_FRAMES_84 && kind != ALEPPO_FRAMES_RAW_PAIR)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown frame kind");
+  if (c->t >= c->T)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "rollout buffer is full: call aleppo_finish_rollout");
+  if (c->prof_on || c->dbg_no_publish)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "aleppo_arm_step is not available while per-kernel profiling is on");
+  const uint8_t *df = nullptr;
+  int rc = upload_frames(c, frames, kind, ALEPPO_HOST_MAPPED, &df);
+  if (rc)
+    return rc;
+  void *sdev = nullptr;
+  if (hipHostGetDevicePointer(&sdev, const_cast<uint8_t *>(episode_start_mapped), 0) != hipSuccess || !sdev)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT,
+                   "episode_start_mapped must lie in mapped page-locked host memory (aleppo_host_alloc)");
+  uint32_t *go_dev = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&go_dev), c->h_go, 0));
+  c->go_seq++;
+  hipError_t e = hipStreamWaitValue32(c->stream, go_dev, c->go_seq, hipStreamWaitValueGte, 0xFFFFFFFFu);
+  if (e != hipSuccess) {
+    c->go_seq--;
+    HIPCHK(c, e);
+  }
+  rc = step_enqueue(c, df, kind, ALEPPO_HOST_MAPPED, nullptr, episode_start_mapped, c->t);
+  if (rc == ALEPPO_OK && c->t + 1 < c->T) {
+    rc = act_enqueue(c, noise_next, c->t + 1);
+    c->act_queued_slot = c->t + 1;
+    c->act_queued_ticket = c->ticket;
+  }
+  if (rc || hipGetLastError() != hipSuccess) { // never leave the stream parked on the release word
+    __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
+    hipStreamSynchronize(c->stream);
+    c->act_queued_slot = -1;
+    return rc ? rc : set_err(c, ALEPPO_ERR_HIP, "aleppo_arm_step: launch failed");
+  }
+  c->armed = true;
+  c->armed_start = episode_start_mapped;
+  return ALEPPO_OK;
+}
+extern "C" int aleppo_release_step(aleppo_ctx *c, const float *rewards, const uint8_t *terminated,
+                                   const uint8_t *truncated) {
+  CHECK_CTX(c);
+  if (!c->armed)
+    return set_err(c, ALEPPO_ERR_RUNTIME, "aleppo_release_step without an armed step");
+  // the frames and the episode-start bytes are in place: let the stream go FIRST, the bookkeeping is off its path
+  std::atomic_thread_fence(std::memory_order_release);
+  __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
+  c->armed = false;
+  if (!rewards || !terminated || !truncated)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  const int E = c->E;
+  uint8_t *rec = c->h_rec + (size_t)c->t * c->step_rec_bytes; // uploaded at finish_rollout
+  std::memcpy(rec, rewards, (size_t)E * 4);
+  std::memcpy(rec + 4 * (size_t)E, terminated, E);
+  std::memcpy(rec + 5 * (size_t)E, truncated, E);
+  std::memcpy(rec + 6 * (size_t)E, c->armed_start, E);
   c->t++;
   return ALEPPO_OK;
 }
@@ -797,7 +895,8 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
   auto release_all = [&]() { // (error paths: never leave the stream parked on the flag)
     __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
   };
-  int rc = act_enqueue(c, noise_at(0));
+  CHECK_NOT_ARMED(c);
+  int rc = act_enqueue(c, noise_at(0), 0);
   if (rc)
     return rc;
   for (int t = 0; t < c->T; ++t) {
@@ -820,7 +919,7 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
     rc = aleppo_step(c, frames + (size_t)t * slot_stride_bytes, kind, location, rewards + (size_t)t * E,
                      terminated + (size_t)t * E, truncated + (size_t)t * E, episode_start + (size_t)t * E);
     if (rc == ALEPPO_OK && t + 1 < c->T)
-      rc = act_enqueue(c, noise_at(t + 1));
+      rc = act_enqueue(c, noise_at(t + 1), t + 1);
     if (gated) {
       if (rc) {
         release_all();
@@ -865,6 +964,8 @@ extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
 
 extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   CHECK_CTX(c);
+  CHECK_NOT_ARMED(c);
+  c->act_queued_slot = -1;
   if (c->t != c->T)
     return set_err(c, ALEPPO_ERR_RUNTIME, "Buffer is not full, cannot compute GAE."); // buffer.cc:64-65
   const int E = c->E, T = c->T, A = c->A;
@@ -934,6 +1035,7 @@ static int ensure_metric_storage(aleppo_ctx *c, int epochs, int M, long B) {
 
 extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_minibatch_metrics *out) {
   CHECK_CTX(c);
+  CHECK_NOT_ARMED(c);
   if (epochs <= 0 || M <= 0)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "epochs and num_mini_batches must be positive");
   const long N = c->batch_n;

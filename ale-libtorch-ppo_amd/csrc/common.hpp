@@ -105,6 +105,11 @@ struct Ctx {
   uint32_t *h_go = nullptr;    // pinned, GPU-visible: the stream waits on it (hipStreamWaitValue32) before a gated slot
   uint32_t go_seq = 0;         // last value the stream was told to wait for / the host released
   unsigned noise_flip = 0;
+  // aleppo_arm_step / aleppo_release_step: a step (and the next slot's acting kernels) enqueued behind the release word
+  bool armed = false;
+  const uint8_t *armed_start = nullptr; // the caller's mapped episode-start bytes of the armed step
+  int act_queued_slot = -1;             // slot whose acting kernels + head are already enqueued (aleppo_act only waits)
+  long long act_queued_ticket = 0;
   // pinned host staging
   int64_t *h_actions = nullptr; // [E]
   uint8_t *h_step = nullptr;    // one step record (aleppo_record_step path)
@@ -282,7 +287,7 @@ void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const vo
 void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
                      const float *b2, const void *W3, const float *b3, void *a3, long ns, int ingest_mode = 0,
                      const uint8_t *frames = nullptr, const uint8_t *lut = nullptr, const StartBits *sbits = nullptr,
-                     long src_delta = 0);
+                     long src_delta = 0, const uint8_t *start_bytes = nullptr);
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns);
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns);

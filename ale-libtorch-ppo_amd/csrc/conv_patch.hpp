@@ -457,6 +457,8 @@ struct ActIngestParams {
   uint32_t *obs_rw;      // the observation slots (same array as ActConvParams::obs)
   long src_delta;        // previous slot - acted slot, in u32 pixels (the stack to shift)
   StartBits sbits;       // episode-start flags (bit e of word e / 32)
+  const uint8_t *start_bytes; // != nullptr: the flags as bytes in (mapped host) memory instead - a step enqueued before
+                              // the emulator has produced them (aleppo_arm_step)
 };
 
 // Acting phases use ONE 16-channel atom per wave (8 waves = MA channel atoms x 8/MA pixel lanes): the weights
@@ -563,6 +565,9 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P, ActInges
   uint8_t *slut = sfr + 7168;                           // [256]
   static_assert(2 * RAW_H * RAW_W <= (ACT_X_ELEMS + ACT_A1_ELEMS) * 2 && 7168 + 256 <= ACT_A2_ELEMS * 2, "ingest LDS map");
   auto ingest = [&](long n) {
+    uint32_t start_byte = 0; // (requested first: over PCIe it lands while the frame is staged)
+    if (G.start_bytes)
+      start_byte = G.start_bytes[n];
     const long nn = n + P.map.n0;
     const long off = (nn / P.map.TP) * P.map.s1 + (nn % P.map.TP) * P.map.s0 + P.map.base; // acted slot, u32 pixels
     if constexpr (MODE == 1) {
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(512) void act_conv_kernel(ActConvParams P, ActInges
         R[i] = src[min(tid + 512 * i, 1763)];
     }
     __syncthreads();
-    const bool st = ((G.sbits.w[n >> 5] >> (n & 31)) & 1u) != 0;
+    const bool st = G.start_bytes ? start_byte != 0 : ((G.sbits.w[n >> 5] >> (n & 31)) & 1u) != 0;
     u32x4 *dst = reinterpret_cast<u32x4 *>(G.obs_rw + off);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

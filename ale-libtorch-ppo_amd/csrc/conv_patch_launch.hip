@@ -103,7 +103,8 @@ void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const vo
 
 void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
                      const float *b2, const void *W3, const float *b3, void *a3, long ns, int ingest_mode,
-                     const uint8_t *frames, const uint8_t *lut, const StartBits *sbits, long src_delta) {
+                     const uint8_t *frames, const uint8_t *lut, const StartBits *sbits, long src_delta,
+                     const uint8_t *start_bytes) {
   static bool once = false;
   if (!once) {
     allow_smem(act_conv_kernel<0>, ACT_SMEM);
@@ -120,6 +121,7 @@ void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1
   G.src_delta = src_delta;
   if (sbits)
     G.sbits = *sbits;
+  G.start_bytes = start_bytes;
   const dim3 g((unsigned)std::min<long>(ns, num_cus())), b(512);
   if (ingest_mode == 1)
     hipLaunchKernelGGL(act_conv_kernel<1>, g, b, ACT_SMEM, s, P, G);

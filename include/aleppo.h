@@ -176,6 +176,20 @@ int aleppo_record_step(aleppo_ctx *ctx, const float *rewards, const uint8_t *ter
 int aleppo_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int location, const float *rewards,
                 const uint8_t *terminated, const uint8_t *truncated, const uint8_t *episode_start);
 
+/* The same step with the stream running ONE SLOT AHEAD of the emulator (replaces the launch latency between
+ * rollout.cc:312-313, the actions reaching the workers, and rollout.cc:204-208, the next forward pass).
+ * aleppo_arm_step - called right after aleppo_act returned slot t's actions, BEFORE the emulators are stepped - enqueues
+ * the ingest of the frames the emulators are about to write into `frames` and of the episode-start flags they are about
+ * to write into `episode_start_mapped` (uint8 [E]; both in mapped page-locked memory from aleppo_host_alloc), plus slot
+ * t+1's acting kernels (noise_next: that slot's sampling noise or NULL), all behind a stream wait
+ * (hipStreamWaitValue32) on a release word.  aleppo_release_step - called when the emulators are done - releases the
+ * stream and records slot t's scalars (the per-env writes of rollout.cc:212-227; episode starts are read from
+ * episode_start_mapped); it advances t.  The next aleppo_act only waits for the actions.  Between the two calls every
+ * other stateful entry point fails with ALEPPO_ERR_RUNTIME.  Results are bit-identical to aleppo_act / aleppo_step. */
+int aleppo_arm_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, const uint8_t *episode_start_mapped,
+                    const float *noise_next);
+int aleppo_release_step(aleppo_ctx *ctx, const float *rewards, const uint8_t *terminated, const uint8_t *truncated);
+
 /* Rollout::rollout()'s slot loop (rollout.cc:198-278) over a PRE-RECORDED environment trace: for t in [0, T):
  * aleppo_act (built-in RNG) then aleppo_step with slot t of the trace.  frames: DEVICE memory, slot t at
  * frames + t * slot_stride_bytes (16-byte aligned); rewards [T][E] f32 and terminated / truncated / episode_start

@@ -430,6 +430,62 @@ def test_engines_trained_concurrently_from_threads_match_engines_trained_alone(p
         np.testing.assert_array_equal(alone[k][1], together[k][1], err_msg=f"engine {k}: parameters")
 
 
+@pytest.mark.parametrize("prec,kind,generic", [("bf16", "84", 0), ("bf16", "raw", 0), ("fp32", "84", 0), ("bf16", "84", 1)])
+def test_armed_live_loop_equals_the_plain_act_step_loop(pkg, prec, kind, generic):
+    """aleppo_arm_step / aleppo_release_step (the stream one slot ahead of the emulator, behind hipStreamWaitValue32): the
+    emulator here is this test - after every aleppo_act it writes the slot's frames and episode-start bytes into mapped
+    host memory and only then releases.  Every stored plane equals the plain aleppo_act / aleppo_step loop on the same
+    trace (fused ingest + acting launch, stand-alone ingest kernel, fp32 generic kernels), two rollouts back to back."""
+    E, T, A, H = 37, 9, 6, 64 if prec == "fp32" else 512
+    raw = kind == "raw"
+    fbytes = E * (2 * 210 * 160 if raw else 7056)
+    fkind = pkg.FRAMES_RAW_PAIR if raw else pkg.FRAMES_84
+    frames = hf.hf_bytes(2510, (2 * T, fbytes))
+    te, tr, st = _flags(2511, 2 * T, E)
+    rew = hf.hf_range(2512, (2 * T, E), -2, 2)
+    noise = -np.log(np.clip(hf.hf_unit(2513, (2 * T + 2) * E * A).reshape(2 * T + 2, E, A), 1e-6, 1.0)).astype(np.float32)
+    keys = ("observations", "actions", "values", "logits", "advantages", "returns", "masks", "rewards", "terminals")
+    got = {}
+    for armed in (0, 1):
+        eng = pkg.Engine(E, T, A, H, precision=pkg.BF16 if prec == "bf16" else pkg.FP32, seed=5)
+        eng.set_generic_conv(generic)
+        eng.load_params(hf.fill_params(2514, H, A))
+        fbuf, sbuf = eng.host_alloc(fbytes), eng.host_alloc(E)
+        planes, k = [], 0
+        for r in range(2):
+            for t in range(T):
+                g = r * T + t
+                actions = eng.act(noise[k]).copy() if not (armed and t > 0) else eng.act().copy()
+                k += 1
+                assert actions.min() >= 0 and actions.max() < A
+                if armed:
+                    # the next slot's head is enqueued now, with ITS noise; the emulator has not produced anything yet
+                    eng.arm_step(fbuf, sbuf, fkind, noise_next=noise[k] if t + 1 < T else None)
+                    with pytest.raises(pkg.AleppoError):
+                        eng.finish_rollout()  # every other stateful call is refused while a step is armed
+                    ctypes.memmove(fbuf, frames[g].ctypes.data, fbytes)
+                    ctypes.memmove(sbuf, st[g].ctypes.data, E)
+                    eng.release_step(rew[g], te[g], tr[g])
+                else:
+                    ctypes.memmove(fbuf, frames[g].ctypes.data, fbytes)
+                    self_st = st[g]
+                    lib = pkg.lib()
+                    rc = lib.aleppo_step(eng._ctx, ctypes.c_void_p(fbuf), fkind, pkg.HOST_MAPPED, rew[g].ctypes.data_as(ctypes.c_void_p),
+                                         te[g].ctypes.data_as(ctypes.c_void_p), tr[g].ctypes.data_as(ctypes.c_void_p),
+                                         self_st.ctypes.data_as(ctypes.c_void_p))
+                    assert rc == 0, eng.last_error() if hasattr(eng, "last_error") else rc
+            eng.finish_rollout(noise[k])
+            k += 1
+            planes.append({q: eng.read_batch(q) for q in keys})
+        got[armed] = planes
+        eng.host_free(fbuf)
+        eng.host_free(sbuf)
+        eng.close()
+    for r in range(2):
+        for q in keys:
+            np.testing.assert_array_equal(got[0][r][q], got[1][r][q], err_msg=f"rollout {r}: {q}")
+
+
 def test_rollouts_run_concurrently_from_threads_match_rollouts_run_alone(pkg):
     """the acting path of two contexts at the same time (own pinned action buffer, ticket word and device counter each):
     every stored plane equals the same rollout run alone"""

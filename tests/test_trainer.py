@@ -155,3 +155,31 @@ def test_trains_debug_config_and_writes_event_file(trainer, tmp_path, precision)
                 b"record_video", b"cuda_graph", b"deterministic"):
         assert key in hp, key
     assert len(payloads) >= 2 + 4 * 14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["bf16", "fp32+rawframes"])
+def test_slot_ahead_loop_trains_to_the_same_parameters(trainer, tmp_path, variant):
+    """`slot_ahead: true` (default; aleppo_arm_step before the emulator threads run, aleppo_release_step after) against
+    `slot_ahead: false` (aleppo_step): same actions, same episodes, bit-identical parameters after 3 rollouts + updates"""
+    import re
+    import numpy as np
+    txt = open(os.path.join(ROOT, "trainer", "configs", "debug.yaml")).read().replace("num_rollouts: 10", "num_rollouts: 3")
+    if "rawframes" in variant:
+        txt += "device_preprocess: true\n"
+    txt = txt.replace("precision: fp32", f"precision: {variant.split('+')[0]}")
+    out = {}
+    for ahead in ("true", "false"):
+        d = tmp_path / ahead
+        os.makedirs(d / "tb")
+        cfg = d / "debug.yaml"
+        cfg.write_text(txt + f"slot_ahead: {ahead}\n")
+        dump = d / "final.bin"
+        r = subprocess.run([trainer, "breakout.bin", str(d / "tb" / "run.log"), str(d), "grp", str(cfg)], capture_output=True,
+                           text=True, timeout=300, env=dict(os.environ, ALEPPO_TRAINER_DUMP_FINAL=str(dump)))
+        assert r.returncode == 0, r.stderr
+        mo = re.search(r"steps (\d+) episodes (\d+) pending_starts (\d+) slots (\d+)", r.stdout)
+        out[ahead] = (tuple(map(int, mo.groups())), np.fromfile(dump, np.float32))
+    assert out["true"][0] == out["false"][0]
+    assert out["true"][0][1] > 0
+    np.testing.assert_array_equal(out["true"][1], out["false"][1])

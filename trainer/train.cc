@@ -26,7 +26,9 @@
 // max_return).  The rom argument is accepted and recorded but not opened.
 // New OPTIONAL yaml keys (defaults reproduce the reference): precision: fp32|bf16, rollout_precision: fp32|fp16,
 // device_preprocess: false (true: the emulators hand over RAW 210x160 frame pairs and the device does gray LUT + resize +
-// max), advantage_norm: false, action_size (honoured here; the reference hard-codes 4, Q4), seed.
+// max), advantage_norm: false, action_size (honoured here; the reference hard-codes 4, Q4), seed,
+// slot_ahead: true (the next slot's ingest + acting kernels are enqueued BEFORE the emulator threads run, behind a stream
+// wait that aleppo_release_step lifts when they are done: aleppo_arm_step in include/aleppo.h; false: aleppo_step).
 // Data parallelism (no reference counterpart): start one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK
 // in the environment (torchrun / mpirun style).  Rank r owns the contiguous environment block
 // [r * E / W, (r + 1) * E / W) and GPU LOCAL_RANK; rank 0 creates the RCCL id, hands it to the others through the file
@@ -70,6 +72,7 @@ struct Config {
   // extensions
   std::string precision = "fp32", rollout_precision = "fp32";
   bool device_preprocess = false; // emulators hand over raw frame pairs; gray LUT + resize + max run on the device (N2)
+  bool slot_ahead = true;         // aleppo_arm_step / aleppo_release_step: the stream runs one slot ahead of the emulators
   bool advantage_norm = false;
   uint64_t seed = 42;
 };
@@ -146,6 +149,7 @@ static Config load_config(const std::string &path) { // keys / defaults of src/b
   c.precision = as<std::string>(kv, "precision", "fp32");
   c.rollout_precision = as<std::string>(kv, "rollout_precision", "fp32");
   c.device_preprocess = as_bool(kv, "device_preprocess", false);
+  c.slot_ahead = as_bool(kv, "slot_ahead", true);
   c.advantage_norm = as_bool(kv, "advantage_norm", false);
   c.seed = as<uint64_t>(kv, "seed", 42);
   return c;
@@ -775,6 +779,10 @@ int main(int argc, char **argv) {
         lut[i] = (uint8_t)i;
       check(ctx, aleppo_set_gray_lut(ctx, lut));
     }
+    // episode-start flags at slot entry, where the armed ingest kernel reads them (mapped like the frames)
+    uint8_t *start_mapped = nullptr;
+    check(ctx, aleppo_host_alloc(ctx, E, reinterpret_cast<void **>(&start_mapped)));
+    const bool slot_ahead = cfg.slot_ahead && !prof.on(); // (per-kernel device profiling brackets every launch)
     std::vector<uint8_t> start_cpu(E, 1), term(E, 0), trunc(E, 0), game_over(E, 0);
     std::vector<float> rewards(E, 0.f), ep_ret(E, 0.f), game_ret(E, 0.f);
     std::vector<size_t> ep_len(E, 0), game_len(E, 0);
@@ -804,11 +812,16 @@ int main(int argc, char **argv) {
           Profile::Span sp(&prof, "aleppo_act");
           check(ctx, aleppo_act(ctx, nullptr, &actions));
         }
+        std::vector<uint8_t> start_at_entry = start_cpu;
+        const int fkind = cfg.device_preprocess ? ALEPPO_FRAMES_RAW_PAIR : ALEPPO_FRAMES_84;
+        if (slot_ahead) { // slot t + 1's kernels go onto the stream now; they start when release_step lifts the wait
+          std::memcpy(start_mapped, start_at_entry.data(), E);
+          check(ctx, aleppo_arm_step(ctx, frames, fkind, start_mapped, nullptr));
+        }
         {
           Profile::Span sp(&prof, "step_all (emulator threads)");
           pool.run_all(E);
         }
-        std::vector<uint8_t> start_at_entry = start_cpu;
         for (size_t i = 0; i < E; ++i) {
           if (!start_cpu[i]) { // rollout.cc:214-226 (start slots keep the stale reward)
             rewards[i] = results[i].reward;
@@ -822,10 +835,12 @@ int main(int argc, char **argv) {
             total_steps++;
           }
         }
-        {
+        if (slot_ahead) {
+          check(ctx, aleppo_release_step(ctx, rewards.data(), term.data(), trunc.data()));
+        } else {
           Profile::Span sp(&prof, "aleppo_step");
-          check(ctx, aleppo_step(ctx, frames, cfg.device_preprocess ? ALEPPO_FRAMES_RAW_PAIR : ALEPPO_FRAMES_84,
-                                 ALEPPO_HOST_MAPPED, rewards.data(), term.data(), trunc.data(), start_at_entry.data()));
+          check(ctx, aleppo_step(ctx, frames, fkind, ALEPPO_HOST_MAPPED, rewards.data(), term.data(), trunc.data(),
+                                 start_at_entry.data()));
         }
         for (size_t i = 0; i < E; ++i) { // rollout.cc:239-265
           if (results[i].terminated || results[i].truncated) {
@@ -942,7 +957,16 @@ int main(int argc, char **argv) {
       prof.device_summary(ctx);
       prof.save();
     }
+    if (const char *dump = std::getenv("ALEPPO_TRAINER_DUMP_FINAL")) { // test hook: the trained parameters
+      size_t n = 0;
+      check(ctx, aleppo_param_count(ctx, &n));
+      std::vector<float> p(n);
+      check(ctx, aleppo_export_params(ctx, p.data(), n));
+      std::ofstream f(dump, std::ios::binary);
+      f.write(reinterpret_cast<const char *>(p.data()), (std::streamsize)(n * sizeof(float)));
+    }
     check(ctx, aleppo_host_free(ctx, frames));
+    check(ctx, aleppo_host_free(ctx, start_mapped));
     aleppo_destroy(ctx);
     std::cout << "Success" << std::endl;
     return 0;
