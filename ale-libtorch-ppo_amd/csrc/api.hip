@@ -139,13 +139,23 @@ void params_to_reference(const ParamLayout &L, const float *internal, float *ref
 // ------------------------------------------------------------------ helpers
 // every stateful entry point: the caller's thread may have another device current, and the kernel-selection switches
 // are this context's
-#define CHECK_CTX(c)                                                                                                   \
+#define CHECK_CTX_ANY(c)                                                                                               \
   do {                                                                                                                 \
     if (!(c))                                                                                                          \
       return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "null context");                                            \
     if (hipSetDevice((c)->cfg.device_ordinal) != hipSuccess)                                                           \
       return set_err(const_cast<aleppo_ctx *>(c), ALEPPO_ERR_HIP, "hipSetDevice failed");                              \
     set_tuning(&(c)->tune);                                                                                            \
+  } while (0)
+// Between aleppo_arm_step and aleppo_release_step the stream is parked on the release word: anything that enqueues behind
+// it and then waits (or rewrites what the parked kernels read) would dead-lock, so every entry point but the release
+// refuses.
+#define CHECK_CTX(c)                                                                                                   \
+  do {                                                                                                                 \
+    CHECK_CTX_ANY(c);                                                                                                  \
+    if ((c)->armed)                                                                                                    \
+      return set_err(const_cast<aleppo_ctx *>(c), ALEPPO_ERR_RUNTIME,                                                  \
+                     "a step is armed: call aleppo_release_step first");                                               \
   } while (0)
 #define CHECK_ASYNC(c)                                                                                                 \
   do {                                                                                                                 \
@@ -619,14 +629,8 @@ static int act_wait(aleppo_ctx *c, long long ticket) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return ALEPPO_OK;
 }
-#define CHECK_NOT_ARMED(c)                                                                                             \
-  do {                                                                                                                 \
-    if ((c)->armed)                                                                                                    \
-      return set_err(c, ALEPPO_ERR_RUNTIME, "a step is armed: call aleppo_release_step first");                        \
-  } while (0)
 extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **actions_pinned) {
   CHECK_CTX(c);
-  CHECK_NOT_ARMED(c);
   int rc = ALEPPO_OK;
   if (c->act_queued_slot == c->t && c->t < c->T) { // enqueued by aleppo_arm_step (with ITS noise): only the wait is left
     c->act_queued_slot = -1;
@@ -754,7 +758,6 @@ static int step_enqueue(aleppo_ctx *c, const uint8_t *df, int kind, int location
 extern "C" int aleppo_push_frames(aleppo_ctx *c, const uint8_t *frames, int kind, int location,
                                   const uint8_t *episode_start) {
   CHECK_CTX(c);
-  CHECK_NOT_ARMED(c);
   int rc = do_push(c, frames, kind, location, episode_start);
   if (rc == ALEPPO_OK)
     HIPCHK(c, hipEventRecord(c->ev_tmp, c->stream));
@@ -769,7 +772,6 @@ extern "C" int aleppo_record_step(aleppo_ctx *c, const float *rewards, const uin
 extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int location, const float *rewards,
                            const uint8_t *terminated, const uint8_t *truncated, const uint8_t *episode_start) {
   CHECK_CTX(c);
-  CHECK_NOT_ARMED(c);
   if (!frames || !rewards || !terminated || !truncated || !episode_start)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
   if (kind != ALEPPO_FRAMES_84 && kind != ALEPPO_FRAMES_RAW_PAIR)
@@ -808,7 +810,6 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
 extern "C" int aleppo_arm_step(aleppo_ctx *c, const uint8_t *frames, int kind, const uint8_t *episode_start_mapped,
                                const float *noise_next) {
   CHECK_CTX(c);
-  CHECK_NOT_ARMED(c);
   if (!frames || !episode_start_mapped)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
   if (kind != ALEPPO_FRAMES_84 && kind != ALEPPO_FRAMES_RAW_PAIR)
@@ -851,7 +852,7 @@ extern "C" int aleppo_arm_step(aleppo_ctx *c, const uint8_t *frames, int kind, c
 }
 extern "C" int aleppo_release_step(aleppo_ctx *c, const float *rewards, const uint8_t *terminated,
                                    const uint8_t *truncated) {
-  CHECK_CTX(c);
+  CHECK_CTX_ANY(c);
   if (!c->armed)
     return set_err(c, ALEPPO_ERR_RUNTIME, "aleppo_release_step without an armed step");
   // the frames and the episode-start bytes are in place: let the stream go FIRST, the bookkeeping is off its path
@@ -895,7 +896,6 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
   auto release_all = [&]() { // (error paths: never leave the stream parked on the flag)
     __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
   };
-  CHECK_NOT_ARMED(c);
   int rc = act_enqueue(c, noise_at(0), 0);
   if (rc)
     return rc;
@@ -964,7 +964,6 @@ extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
 
 extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   CHECK_CTX(c);
-  CHECK_NOT_ARMED(c);
   c->act_queued_slot = -1;
   if (c->t != c->T)
     return set_err(c, ALEPPO_ERR_RUNTIME, "Buffer is not full, cannot compute GAE."); // buffer.cc:64-65
@@ -1035,7 +1034,6 @@ static int ensure_metric_storage(aleppo_ctx *c, int epochs, int M, long B) {
 
 extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_minibatch_metrics *out) {
   CHECK_CTX(c);
-  CHECK_NOT_ARMED(c);
   if (epochs <= 0 || M <= 0)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "epochs and num_mini_batches must be positive");
   const long N = c->batch_n;
