@@ -486,6 +486,19 @@ def test_armed_live_loop_equals_the_plain_act_step_loop(pkg, prec, kind, generic
             np.testing.assert_array_equal(got[0][r][q], got[1][r][q], err_msg=f"rollout {r}: {q}")
 
 
+def test_gated_replay_equals_launch_per_slot_replay():
+    """aleppo_replay_rollout with the stream one slot ahead of the host (hipStreamWaitValue32 on the release word, the
+    default) against ALEPPO_REPLAY_GATED=0 (a launch per slot after the actions arrived): the same bits in every stored
+    plane at T = 1, T = 2, more environments than CUs, 18 actions, and the benched E = 128"""
+    out = {}
+    for gated in ("1", "0"):
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "replay_digest.py")],
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, ALEPPO_REPLAY_GATED=gated))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[gated] = [l for l in r.stdout.splitlines() if l.startswith("digest")][-1]
+    assert out["1"] == out["0"]
+
+
 def test_rollouts_run_concurrently_from_threads_match_rollouts_run_alone(pkg):
     """the acting path of two contexts at the same time (own pinned action buffer, ticket word and device counter each):
     every stored plane equals the same rollout run alone"""
