@@ -6,6 +6,7 @@
 #include <cmath>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <rccl/rccl.h>
 
@@ -612,16 +613,26 @@ static int act_enqueue(aleppo_ctx *c, const float *noise, int slot) {
   return do_act(c, noise, slot, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
 }
 // wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
-static int act_wait(aleppo_ctx *c, long long ticket) {
+// stream_parked: the stream already holds the NEXT slot behind the release word (gated replay) - a stream sync would
+// wait for a release only this thread can give, so the wait only spins (and yields once the slot is clearly a long one)
+static int act_wait(aleppo_ctx *c, long long ticket, bool stream_parked = false) {
   volatile long long *tk = reinterpret_cast<volatile long long *>(c->h_actions + c->E);
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
+  bool slow = false;
   if (c->dbg_no_publish)
     HIPCHK(c, hipStreamSynchronize(c->stream));
   while (!c->dbg_no_publish && *tk != ticket) {
-    __builtin_ia32_pause();
-    if ((++spins & 1023u) == 0 &&
+    if (slow)
+      std::this_thread::yield();
+    else
+      __builtin_ia32_pause();
+    if (!slow && (++spins & 1023u) == 0 &&
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
+      if (stream_parked) {
+        slow = true;
+        continue;
+      }
       HIPCHK(c, hipStreamSynchronize(c->stream));
       break;
     }
@@ -926,7 +937,7 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
         hipStreamSynchronize(c->stream);
         return rc;
       }
-      rc = act_wait(c, ticket_t); // the host has slot t's actions: the emulator would step now
+      rc = act_wait(c, ticket_t, /*stream_parked=*/true); // the host has slot t's actions: the emulator would step now
       release_all();              // ... and hand over slot t + 1's frames
       if (rc)
         return rc;
