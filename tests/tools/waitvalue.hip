@@ -54,5 +54,43 @@ int main() {
     CK(hipStreamSynchronize(s));
     std::printf("(b) pre-enqueued wait-value: %.2f us per slot\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / T);
   }
+  // (c) the release word in fine-grained DEVICE memory, written by the host through the BAR (a posted PCIe write) and
+  //     polled by the GPU locally - if this system maps such memory into the host's address space
+  {
+    unsigned int *dflag = nullptr;
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&dflag), 64, hipDeviceMallocFinegrained);
+    hipPointerAttribute_t attr{};
+    if (e != hipSuccess || hipPointerGetAttributes(&attr, dflag) != hipSuccess) {
+      std::printf("(c) fine-grained device memory: not available (%s)\n", hipGetErrorString(e));
+      return 0;
+    }
+    int host_ok = 0;
+    CK(hipDeviceGetAttribute(&host_ok, hipDeviceAttributeDirectManagedMemAccessFromHost, 0));
+    std::printf("(c) fine-grained device flag at %p, hostPointer %p, DirectManagedMemAccessFromHost %d\n", (void *)dflag,
+                attr.hostPointer, host_ok);
+    if (!attr.hostPointer) {
+      std::printf("(c) no host mapping reported: skipped\n");
+      return 0;
+    }
+    volatile unsigned int *hf = reinterpret_cast<volatile unsigned int *>(attr.hostPointer);
+    CK(hipMemset(dflag, 0, 64));
+    for (int rep = 0; rep < 2; ++rep) {
+      *vt = 0;
+      const unsigned base = rep * T;
+      for (unsigned int t = 1; t <= (unsigned)T; ++t) {
+        CK(hipStreamWaitValue32(s, dflag, base + t, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        hipLaunchKernelGGL(slot_kernel, dim3(1), dim3(64), 0, s, ticket, t);
+      }
+      auto t0 = std::chrono::steady_clock::now();
+      for (unsigned int t = 1; t <= (unsigned)T; ++t) {
+        *hf = base + t;
+        while (*vt != t) {
+        }
+      }
+      auto t1 = std::chrono::steady_clock::now();
+      CK(hipStreamSynchronize(s));
+      std::printf("(c) release word in device memory: %.2f us per slot\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / T);
+    }
+  }
   return 0;
 }
