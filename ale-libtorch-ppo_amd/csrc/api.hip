@@ -1151,14 +1151,15 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       // bucket 0 is reduced early only for the all-reduce overlap: on one GPU an early reduce next to the conv dgrads
       // measured slower (8.60 vs 8.38 ms per update) than one reduce of all ten slab groups at the end
       const bool early0 = dp;
-      if (early0) {
-        prof_begin(c, ALEPPO_K_REDUCE, sw);
-        launch_reduce_slabs(sw, segs0, nseg0, c->G);
-        prof_end(c, ALEPPO_K_REDUCE, sw);
-      }
-      if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs
+      if (dp) { // bucket 0 (heads + fc = 95% of the bytes) travels while the conv backward runs.  Its slab reduce runs on
+                // the communication stream too, in front of the all-reduce: on the weight-gradient stream it sat between
+                // the fc and the conv weight gradients and that stream, not the dgrad chain, ended the minibatch (trace
+                // with a 1-rank communicator: conv1 wgrad done at 419 us, conv2 wgrad at 453 us).
         HIPCHK(c, hipEventRecord(c->ev_bucket0, sw));
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
+        prof_begin(c, ALEPPO_K_REDUCE, c->comm_stream);
+        launch_reduce_slabs(c->comm_stream, segs0, nseg0, c->G);
+        prof_end(c, ALEPPO_K_REDUCE, c->comm_stream);
         NCCLCHK(c, ncclAllReduce(c->G, c->G, L.bucket0_end, ncclFloat, ncclSum, comm, c->comm_stream));
         HIPCHK(c, hipEventRecord(c->ev_comm0, c->comm_stream));
       }

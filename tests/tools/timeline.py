@@ -1,4 +1,5 @@
-"""print the kernel timeline (start / end in us, queue) of the last complete minibatch in a rocprofv3 kernel-trace CSV"""
+"""print the kernel timeline (start / end in us, queue) of one minibatch in a rocprofv3 kernel-trace CSV:
+    timeline.py <dir> [k]   (k: index of the Adam launch that precedes it; default: the last complete minibatch)"""
 import csv, glob, sys, re
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -7,7 +8,8 @@ def short(n):
     n = re.sub(r"\(.*", "", n); n = n.replace("aleppo::", "")
     return n[:70]
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-a, b = adam[-3], adam[-2]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 3  # which minibatch (index of the Adam launch BEFORE it)
+a, b = adam[k], adam[k + 1]
 t0 = int(rows[a]["End_Timestamp"])
 for r in rows[a:b + 1]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
