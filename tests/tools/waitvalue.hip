@@ -14,6 +14,20 @@ __global__ void slot_kernel(volatile unsigned int *ticket, unsigned int t) {
     __hip_atomic_store(const_cast<unsigned int *>(ticket), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// (d) the slot's kernel itself waits for the release after it has published its ticket (bounded spin on the host word)
+__global__ void slot_wait_kernel(volatile unsigned int *ticket, unsigned int t, const unsigned int *go, unsigned int *timeouts) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __hip_atomic_store(const_cast<unsigned int *>(ticket), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < t) {
+      if (wall_clock64() - t0 > 200000000ull) { // 2 s at 100 MHz
+        atomicAdd(timeouts, 1u);
+        break;
+      }
+    }
+  }
+}
+
 int main() {
   const int T = 2000;
   unsigned int *ticket, *flag;
@@ -53,6 +67,29 @@ int main() {
     auto t1 = std::chrono::steady_clock::now();
     CK(hipStreamSynchronize(s));
     std::printf("(b) pre-enqueued wait-value: %.2f us per slot\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / T);
+  }
+  {
+    unsigned int *timeouts;
+    CK(hipMalloc(&timeouts, 4));
+    CK(hipMemset(timeouts, 0, 4));
+    __atomic_store_n(flag, 0u, __ATOMIC_RELEASE);
+    for (int rep = 0; rep < 2; ++rep) {
+      const unsigned base = (unsigned)rep * T; // tickets / release values base + 1 .. base + T (monotonic across reps)
+      for (unsigned int t = 1; t <= (unsigned)T; ++t)
+        hipLaunchKernelGGL(slot_wait_kernel, dim3(1), dim3(64), 0, s, ticket, base + t, flag, timeouts);
+      auto t0 = std::chrono::steady_clock::now();
+      for (unsigned int t = 1; t <= (unsigned)T; ++t) {
+        while (*vt != base + t) {
+        }
+        __atomic_store_n(flag, base + t, __ATOMIC_RELEASE);
+      }
+      auto t1 = std::chrono::steady_clock::now();
+      CK(hipStreamSynchronize(s));
+      unsigned int to = 0;
+      CK(hipMemcpy(&to, timeouts, 4, hipMemcpyDeviceToHost));
+      std::printf("(d) the slot kernel waits for its own release: %.2f us per slot (timeouts %u)\n",
+                  std::chrono::duration<double, std::micro>(t1 - t0).count() / T, to);
+    }
   }
   // (c) the release word in fine-grained DEVICE memory, written by the host through the BAR (a posted PCIe write) and
   //     polled by the GPU locally - if this system maps such memory into the host's address space
