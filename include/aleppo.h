@@ -184,7 +184,8 @@ int aleppo_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int loca
  * t+1's acting kernels (noise_next: that slot's sampling noise or NULL), all behind a stream wait
  * (hipStreamWaitValue32) on a release word.  aleppo_release_step - called when the emulators are done - releases the
  * stream and records slot t's scalars (the per-env writes of rollout.cc:212-227; episode starts are read from
- * episode_start_mapped); it advances t.  The next aleppo_act only waits for the actions.  Between the two calls every
+ * episode_start_mapped); it advances t.  The next aleppo_act only waits for the actions (its noise argument is ignored:
+ * that head is already on the stream with noise_next).  Between the two calls every
  * other stateful entry point fails with ALEPPO_ERR_RUNTIME.  Results are bit-identical to aleppo_act / aleppo_step. */
 int aleppo_arm_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, const uint8_t *episode_start_mapped,
                     const float *noise_next);
