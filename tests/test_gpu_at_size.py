@@ -378,6 +378,58 @@ def test_captured_update_graph_is_bit_identical_to_eager(pkg, prec):
     assert np.abs(eager[0][3][2] - eager[0][2][2]).max() > 0  # the replays kept learning
 
 
+THREADS = pytest.mark.skipif(not os.environ.get("ALEPPO_TEST_THREADS"),
+                             reason="multi-threaded use of several contexts: opt-in (ALEPPO_TEST_THREADS=1); see DESIGN.md 6")
+
+
+def test_contexts_used_alternately_match_contexts_used_alone(pkg):
+    """Three contexts alive at the same time (different kernel switches, different precisions) and driven ALTERNATELY from
+    one thread - update calls and whole rollouts interleaved: every context carries its own streams, scratch, switches,
+    pinned hand-off words and error state, so each gives the bits it gives when it is the only context of the process
+    (rollout.h keeps everything per Rollout object; ADVICE r1: process-global switches)."""
+    cfgs = [dict(E=64, T=8, A=4, H=512, prec=pkg.BF16, generic=0, seed=2610),
+            dict(E=16, T=8, A=6, H=64, prec=pkg.FP32, generic=0, seed=2620),
+            dict(E=64, T=8, A=6, H=512, prec=pkg.BF16, generic=1, seed=2630)]
+    keys = ("observations", "actions", "values", "advantages", "returns")
+
+    def build(c):
+        E, T = c["E"], c["T"]
+        eng = pkg.Engine(E, T, c["A"], c["H"], precision=c["prec"], seed=c["seed"])
+        eng.set_generic_conv(c["generic"])
+        eng.load_params(hf.fill_params(c["seed"], c["H"], c["A"]))
+        dev = DeviceBytes(hf.hf_bytes(c["seed"] + 1, (T, E, 84, 84)))
+        te, tr, st = _flags(c["seed"] + 2, T, E)
+        return eng, dev, (hf.hf_range(c["seed"] + 3, (T, E), -2, 2), te, tr, st)
+
+    def round_of(item):
+        eng, dev, (rew, te, tr, st) = item
+        eng.replay_rollout(dev.addr, pkg.FRAMES_84, eng.E * 7056, rew, te, tr, st)
+        eng.finish_rollout()
+        planes = [eng.read_batch(q) for q in keys]
+        m = eng.train(2.5e-4, 2, 2)
+        return planes + [m["loss"].copy(), m["grad_norm"].copy(), eng.export_params()]
+
+    alone = []
+    for c in cfgs:
+        item = build(c)
+        alone.append([round_of(item) for _ in range(3)])
+        item[0].close()
+        item[1].free()
+    items = [build(c) for c in cfgs]
+    together = [[] for _ in cfgs]
+    for r in range(3):
+        for k in (2, 0, 1) if r % 2 else (0, 1, 2):
+            together[k].append(round_of(items[k]))
+    for it in items:
+        it[0].close()
+        it[1].free()
+    for k in range(len(cfgs)):
+        for r in range(3):
+            for a, b in zip(alone[k][r], together[k][r]):
+                np.testing.assert_array_equal(a, b, err_msg=f"context {k}, round {r}")
+
+
+@THREADS
 def test_engines_trained_concurrently_from_threads_match_engines_trained_alone(pkg):
     """Two contexts in one process, each driven by its own host thread at the same time (different kernel switches,
     different precisions): every context carries its own streams, scratch, switches and error state, every entry point
@@ -499,6 +551,7 @@ def test_gated_replay_equals_launch_per_slot_replay():
     assert out["1"] == out["0"]
 
 
+@THREADS
 def test_rollouts_run_concurrently_from_threads_match_rollouts_run_alone(pkg):
     """the acting path of two contexts at the same time (own pinned action buffer, ticket word and device counter each):
     every stored plane equals the same rollout run alone"""
