@@ -178,6 +178,12 @@ template <class T> static hipError_t dalloc(T **p, size_t bytes) {
   hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes ? bytes : 16);
   if (e == hipSuccess)
     e = hipMemset(*p, 0, bytes ? bytes : 16);
+  // hipMemset of device memory returns before the fill has run, and it runs on the NULL stream, which the context's
+  // non-blocking streams do not wait for: without this wait a kernel of the context could use the buffer first and have
+  // its results wiped afterwards.  Seen only with other contexts keeping the GPU busy (a late fill of the ticket counter:
+  // the acting head never published; of the metric planes / Adam's step scalars at the first aleppo_train: loss 0, NaN).
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(nullptr);
   return e;
 }
 
@@ -499,6 +505,7 @@ extern "C" int aleppo_load_params(aleppo_ctx *c, const float *flat, size_t count
   HIPCHK(c, hipMemset(c->M1, 0, tmp.size() * 4));
   HIPCHK(c, hipMemset(c->M2, 0, tmp.size() * 4));
   HIPCHK(c, hipMemset(c->G, 0, tmp.size() * 4));
+  HIPCHK(c, hipStreamSynchronize(nullptr)); // (the fills run on the null stream: see dalloc)
   c->adam_step = 0;
   c->pre_acted = -1;
   refresh_compute_copies(c);
