@@ -634,14 +634,19 @@ static int act_wait(aleppo_ctx *c, long long ticket, bool stream_parked = false)
       std::this_thread::yield();
     else
       __builtin_ia32_pause();
-    if (!slow && (++spins & 1023u) == 0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
-      if (stream_parked) {
-        slow = true;
-        continue;
+    if ((++spins & 1023u) == 0) {
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (slow) {
+        if (waited > 60.0) // never spin for ever: a slot does not take a minute
+          return set_err(c, ALEPPO_ERR_RUNTIME, "the acting head's ticket did not arrive within 60 s");
+      } else if (waited > 2e-3) {
+        if (stream_parked) {
+          slow = true;
+          continue;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        break;
       }
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      break;
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
