@@ -45,6 +45,7 @@ KERNEL_CLASSES = dict(ingest=0, gae=1, head=2, adam=3, conv1_fwd=4, conv2_fwd=5,
 # aleppo_set_option keys (include/aleppo.h)
 OPT_GENERIC_CONV, OPT_DEBUG_NO_PUBLISH, OPT_FORCE_COMM, OPT_SERIAL_UPDATE = 0, 1, 2, 3
 OPT_FC_PIPE, OPT_FC_PIPE_WGRAD, OPT_FUSED_ACT, OPT_UPDATE_GRAPH, OPT_FUSE_C2D_C1W = 4, 5, 6, 7, 8
+OPT_GATE_TIMEOUT_MS = 9
 
 EXPORTS = [
     "aleppo_abi_version", "aleppo_create", "aleppo_destroy", "aleppo_last_error", "aleppo_param_count",

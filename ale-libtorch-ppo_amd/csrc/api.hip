@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <mutex>
 #include <cstring>
 #include <rccl/rccl.h>
 
@@ -147,6 +148,8 @@ void params_to_reference(const ParamLayout &L, const float *internal, float *ref
     if (hipSetDevice((c)->cfg.device_ordinal) != hipSuccess)                                                           \
       return set_err(const_cast<aleppo_ctx *>(c), ALEPPO_ERR_HIP, "hipSetDevice failed");                              \
     set_tuning(&(c)->tune);                                                                                            \
+    if ((c)->failed)                                                                                                   \
+      return set_err(const_cast<aleppo_ctx *>(c), ALEPPO_ERR_RUNTIME, (c)->fail_msg);                                  \
   } while (0)
 // Between aleppo_arm_step and aleppo_release_step the stream is parked on the release word: anything that enqueues behind
 // it and then waits (or rewrites what the parked kernels read) would dead-lock, so every entry point but the release
@@ -173,18 +176,47 @@ void params_to_reference(const ParamLayout &L, const float *internal, float *ref
       return set_err((c), ALEPPO_ERR_HIP, std::string(#x) + ": " + ncclGetErrorString(r_));                            \
   } while (0)
 
+// A failure after which the rollout / learner state is undefined: the context refuses every later call (sticky), any
+// gate still on the stream is released so that the stream drains, and nothing is freed or reused before aleppo_destroy
+// (kernels that are still queued may read the caller's frame buffers until then).
+static int fail_ctx(Ctx *c, int code, const std::string &msg) {
+  c->failed = true;
+  c->fail_msg = msg + " - the context is unusable: destroy it";
+  c->armed = false;
+  c->act_queued_slot = -1;
+  if (c->h_go)
+    __atomic_store_n(c->h_go, ~0ull, __ATOMIC_RELEASE);
+  return set_err(c, code, c->fail_msg);
+}
+
 static size_t tsz(const Ctx *c) { return c->prec == ALEPPO_BF16 ? 2 : 4; }
-template <class T> static hipError_t dalloc(T **p, size_t bytes) {
+// A context only ever touches its OWN streams after aleppo_create: no null-stream operation, no hipFree, no
+// hipDeviceSynchronize.  Those calls wait for (hipFree / hipHostFree / hipDeviceSynchronize) or are ordered against
+// (null stream) other streams of the device - and another context's stream may be parked behind its release word,
+// which only ITS owner thread lifts (the cause of the two-context hang of round 2).
+template <class T> static hipError_t dalloc(T **p, size_t bytes, hipStream_t st) {
   hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes ? bytes : 16);
   if (e == hipSuccess)
-    e = hipMemset(*p, 0, bytes ? bytes : 16);
-  // hipMemset of device memory returns before the fill has run, and it runs on the NULL stream, which the context's
-  // non-blocking streams do not wait for: without this wait a kernel of the context could use the buffer first and have
-  // its results wiped afterwards.  Seen only with other contexts keeping the GPU busy (a late fill of the ticket counter:
-  // the acting head never published; of the metric planes / Adam's step scalars at the first aleppo_train: loss 0, NaN).
+    e = hipMemsetAsync(*p, 0, bytes ? bytes : 16, st);
+  // the fill is asynchronous: wait for it, or a kernel on another stream of the context could use the buffer first and
+  // have its results wiped afterwards (round 2: a late fill of the ticket counter / the metric planes)
   if (e == hipSuccess)
-    e = hipStreamSynchronize(nullptr);
+    e = hipStreamSynchronize(st);
   return e;
+}
+// host <-> device copy on the context's main stream, complete when the call returns
+static hipError_t copy_sync(Ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+  return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+}
+// device / pinned-host memory a context has outgrown: kept until aleppo_destroy (see above)
+static void retire(Ctx *c, void *dev) {
+  if (dev)
+    c->retired.push_back(dev);
+}
+static void retire_host(Ctx *c, void *host) {
+  if (host)
+    c->retired_host.push_back(host);
 }
 
 // a failure inside a helper that cannot return a status is kept in the context and reported by CHECK_ASYNC at the end of
@@ -343,8 +375,9 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
     }                                                                                                                  \
   } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-  CK(hipStreamCreateWithFlags(&c->wg_stream, hipStreamNonBlocking));
+  // (the update's two side streams are created by the first aleppo_train: a context that only acts holds ONE stream.
+  // The runtime multiplexes streams onto GPU_MAX_HW_QUEUES - default 4 - hardware queues, and a kernel that lands in the
+  // queue of another context's parked stream waits behind its gate: tests/tools/parkprobe.hip)
   CK(hipEventCreateWithFlags(&c->ev_bucket0, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_comm0, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_comm1, hipEventDisableTiming));
@@ -353,23 +386,23 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
     CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_adam, hipEventDisableTiming));
   CK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
-  CK(dalloc(&c->obs, (size_t)E * (T + 1) * FRAME_PIX * 4));
+  CK(dalloc(&c->obs, (size_t)E * (T + 1) * FRAME_PIX * 4, c->stream));
   c->step_rec_bytes = ((size_t)7 * E + 15) / 16 * 16;
-  CK(dalloc(&c->step_rec, c->step_rec_bytes * T));
-  CK(dalloc(reinterpret_cast<char **>(&c->values_tm), (size_t)(T + 1) * E * c->rsz));
-  CK(dalloc(reinterpret_cast<char **>(&c->logits_tm), (size_t)(T + 1) * E * A * c->rsz));
-  CK(dalloc(&c->actions_tm, (size_t)(T + 1) * E * 4));
-  CK(dalloc(&c->lut, 256));
-  CK(dalloc(&c->d_start, (size_t)E));
-  CK(dalloc(&c->d_frames, (size_t)E * 2 * RAW_H * RAW_W));
-  CK(dalloc(&c->d_noise, (size_t)2 * E * A * 4));
-  CK(dalloc(&c->d_err, 16));
-  CK(dalloc(&c->d_done, 16));
+  CK(dalloc(&c->step_rec, c->step_rec_bytes * T, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->values_tm), (size_t)(T + 1) * E * c->rsz, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->logits_tm), (size_t)(T + 1) * E * A * c->rsz, c->stream));
+  CK(dalloc(&c->actions_tm, (size_t)(T + 1) * E * 4, c->stream));
+  CK(dalloc(&c->lut, 256, c->stream));
+  CK(dalloc(&c->d_start, (size_t)E, c->stream));
+  CK(dalloc(&c->d_frames, (size_t)E * 2 * RAW_H * RAW_W, c->stream));
+  CK(dalloc(&c->d_noise, (size_t)2 * E * A * 4, c->stream));
+  CK(dalloc(&c->d_err, 16, c->stream));
+  CK(dalloc(&c->d_done, 16, c->stream));
   {
     uint8_t ident[256];
     for (int i = 0; i < 256; ++i)
       ident[i] = (uint8_t)i;
-    CK(hipMemcpy(c->lut, ident, 256, hipMemcpyHostToDevice));
+    CK(copy_sync(c, c->lut, ident, 256, hipMemcpyHostToDevice));
   }
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_actions), (size_t)(E + 8) * 8, hipHostMallocMapped));
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_step), c->step_rec_bytes + E, hipHostMallocDefault));
@@ -379,38 +412,45 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_noise), (size_t)2 * E * A * 4, hipHostMallocDefault));
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_go), 64, hipHostMallocMapped));
   std::memset(c->h_go, 0, 64);
+  {
+    // exit condition of the slot-ahead gate (gate_kernel): an emulator step takes milliseconds, so two minutes mean the
+    // host is gone.  ALEPPO_GATE_TIMEOUT_MS / ALEPPO_OPT_GATE_TIMEOUT_MS change it (the tests use 100 ms).
+    const char *e = std::getenv("ALEPPO_GATE_TIMEOUT_MS");
+    const double ms = e ? std::max(1.0, std::atof(e)) : 120000.0;
+    c->gate_timeout_ticks = (unsigned long long)(ms * 1e5); // 100 MHz wall clock
+  }
   CK(hipHostMalloc(reinterpret_cast<void **>(&c->h_err), 16, hipHostMallocDefault));
   std::memset(c->h_actions, 0, (size_t)(E + 8) * 8);
-  CK(dalloc(reinterpret_cast<char **>(&c->adv_n), (size_t)c->N * c->rsz));
-  CK(dalloc(reinterpret_cast<char **>(&c->ret_n), (size_t)c->N * c->rsz));
-  CK(dalloc(reinterpret_cast<char **>(&c->oldlp_n), (size_t)c->N * A * c->rsz));
-  CK(dalloc(&c->act_n, (size_t)c->N * 4));
-  CK(dalloc(&c->mask_n, (size_t)c->N));
-  CK(dalloc(&c->mask_counts, 4096 * 4));
-  CK(dalloc(&c->P, PT * 4));
-  CK(dalloc(&c->G, PT * 4));
-  CK(dalloc(&c->Gs, PT * 4));
-  CK(dalloc(&c->M1, PT * 4));
-  CK(dalloc(&c->M2, PT * 4));
+  CK(dalloc(reinterpret_cast<char **>(&c->adv_n), (size_t)c->N * c->rsz, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->ret_n), (size_t)c->N * c->rsz, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->oldlp_n), (size_t)c->N * A * c->rsz, c->stream));
+  CK(dalloc(&c->act_n, (size_t)c->N * 4, c->stream));
+  CK(dalloc(&c->mask_n, (size_t)c->N, c->stream));
+  CK(dalloc(&c->mask_counts, 4096 * 4, c->stream));
+  CK(dalloc(&c->P, PT * 4, c->stream));
+  CK(dalloc(&c->G, PT * 4, c->stream));
+  CK(dalloc(&c->Gs, PT * 4, c->stream));
+  CK(dalloc(&c->M1, PT * 4, c->stream));
+  CK(dalloc(&c->M2, PT * 4, c->stream));
   if (c->prec == ALEPPO_BF16)
-    CK(dalloc(reinterpret_cast<char **>(&c->Pc), PT * 2));
+    CK(dalloc(reinterpret_cast<char **>(&c->Pc), PT * 2, c->stream));
   else
     c->Pc = c->P;
-  CK(dalloc(reinterpret_cast<char **>(&c->W2d), (size_t)4 * 32 * 256 * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->W3d), (size_t)64 * 576 * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->WfcT), (size_t)FC_IN * H * ts));
+  CK(dalloc(reinterpret_cast<char **>(&c->W2d), (size_t)4 * 32 * 256 * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->W3d), (size_t)64 * 576 * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->WfcT), (size_t)FC_IN * H * ts, c->stream));
   const size_t mb = (size_t)c->maxB;
-  CK(dalloc(reinterpret_cast<char **>(&c->a1), mb * A1_PIX * A1_C * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->a2), mb * A2_PIX * A2_C * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->a3), mb * FC_IN * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->dz1), mb * A1_PIX * A1_C * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->dz2), mb * A2_PIX * A2_C * ts));
-  CK(dalloc(reinterpret_cast<char **>(&c->dz3), mb * FC_IN * ts));
-  CK(dalloc(&c->h, (size_t)FC_FWD_MAX_PARTS * mb * H * 4)); // up to FC_FWD_MAX_PARTS split-K slabs
-  CK(dalloc(&c->hpart, (size_t)FC_SPLITS * E * H * 4));
-  CK(dalloc(reinterpret_cast<char **>(&c->dh), mb * H * ts));
-  CK(dalloc(&c->logits_b, mb * A * 4));
-  CK(dalloc(&c->values_b, mb * 4));
+  CK(dalloc(reinterpret_cast<char **>(&c->a1), mb * A1_PIX * A1_C * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->a2), mb * A2_PIX * A2_C * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->a3), mb * FC_IN * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->dz1), mb * A1_PIX * A1_C * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->dz2), mb * A2_PIX * A2_C * ts, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->dz3), mb * FC_IN * ts, c->stream));
+  CK(dalloc(&c->h, (size_t)FC_FWD_MAX_PARTS * mb * H * 4, c->stream)); // up to FC_FWD_MAX_PARTS split-K slabs
+  CK(dalloc(&c->hpart, (size_t)FC_SPLITS * E * H * 4, c->stream));
+  CK(dalloc(reinterpret_cast<char **>(&c->dh), mb * H * ts, c->stream));
+  CK(dalloc(&c->logits_b, mb * A * 4, c->stream));
+  CK(dalloc(&c->values_b, mb * 4, c->stream));
   // slabs: [W1|b1|W2|b2|W3|b3|Wfc|bfc|Wh|bh]
   c->slab_off[0] = 0;
   const size_t sl[10] = {(size_t)MAXS_C1 * 32 * 256,       (size_t)MAXS_C1 * 32, (size_t)MAXS_C2 * 64 * 512,
@@ -420,10 +460,10 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   for (int i = 0; i < 10; ++i)
     c->slab_off[i + 1] = c->slab_off[i] + align64(sl[i]);
   c->slab_floats = c->slab_off[10];
-  CK(dalloc(&c->slab, c->slab_floats * 4));
-  CK(dalloc(&c->sumsq_part, 1024 * 4));
-  CK(dalloc(&c->adv_stats, 64));
-  CK(hipDeviceSynchronize());
+  CK(dalloc(&c->slab, c->slab_floats * 4, c->stream));
+  CK(dalloc(&c->sumsq_part, 1024 * 4, c->stream));
+  CK(dalloc(&c->adv_stats, 64, c->stream));
+  CK(hipStreamSynchronize(c->stream)); // (own streams only: see dalloc)
 #undef CK
   *out = c;
   return ALEPPO_OK;
@@ -434,9 +474,14 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
     return;
   set_tuning(nullptr);
   (void)hipSetDevice(c->cfg.device_ordinal);
-  if (c->armed && c->h_go) // an armed step parks the stream on the release word: let it go before waiting for the device
-    __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
-  hipDeviceSynchronize();
+  if (c->h_go) // an armed step parks the stream on the release word: let it go before waiting for it
+    __atomic_store_n(c->h_go, ~0ull, __ATOMIC_RELEASE);
+  for (hipStream_t st : {c->wg_stream, c->comm_stream, c->stream})
+    if (st)
+      hipStreamSynchronize(st);
+  // From here on hipFree / hipHostFree: each waits for every stream of the device.  If another context of this process
+  // has a step armed on another thread, that wait lasts until its owner releases it (never call aleppo_destroy from the
+  // thread that owns an armed context: INTEGRATION.md, threading).
   if (c->graph_exec)
     hipGraphExecDestroy(c->graph_exec);
   if (c->graph)
@@ -449,10 +494,12 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
                  c->W2d,   c->W3d,      c->WfcT,      c->a1,        c->a2,         c->a3,      c->dz1,
                  c->dz2,   c->dz3,      c->h,         c->hpart,     c->dh,        c->logits_b,   c->values_b, c->slab,
                  c->sumsq_part, c->metric_ps, c->metric_red, c->grad_norms, c->adv_stats, c->stage_u8, c->stage_obs,
-                 c->adam_sched};
+                 c->adam_sched, c->rb_tmp[0], c->rb_tmp[1]};
   for (void *p : dev)
     if (p)
       hipFree(p);
+  for (void *p : c->retired)
+    hipFree(p);
   if (c->Pc && c->Pc != c->P)
     hipFree(c->Pc);
   void *host[] = {c->h_go, c->h_actions, c->h_step, c->h_rec, c->h_frames, c->h_noise, c->h_err, c->h_metric_red,
@@ -460,6 +507,8 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
   for (void *p : host)
     if (p)
       hipHostFree(p);
+  for (void *p : c->retired_host)
+    hipHostFree(p);
   for (auto &pc : c->prof)
     for (size_t i = 0; i < pc.start.size(); ++i) {
       hipEventDestroy(pc.start[i]);
@@ -480,9 +529,9 @@ extern "C" void aleppo_destroy(aleppo_ctx *c) {
 
 extern "C" int aleppo_synchronize(aleppo_ctx *c) {
   CHECK_CTX(c);
-  HIPCHK(c, hipStreamSynchronize(c->wg_stream));
-  HIPCHK(c, hipStreamSynchronize(c->comm_stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (hipStream_t st : {c->wg_stream, c->comm_stream, c->stream})
+    if (st)
+      HIPCHK(c, hipStreamSynchronize(st));
   return ALEPPO_OK;
 }
 
@@ -501,11 +550,10 @@ extern "C" int aleppo_load_params(aleppo_ctx *c, const float *flat, size_t count
   std::vector<float> tmp(c->L.total());
   params_to_internal(c->L, flat, tmp.data());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->P, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemset(c->M1, 0, tmp.size() * 4));
-  HIPCHK(c, hipMemset(c->M2, 0, tmp.size() * 4));
-  HIPCHK(c, hipMemset(c->G, 0, tmp.size() * 4));
-  HIPCHK(c, hipStreamSynchronize(nullptr)); // (the fills run on the null stream: see dalloc)
+  HIPCHK(c, hipMemsetAsync(c->M1, 0, tmp.size() * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->M2, 0, tmp.size() * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->G, 0, tmp.size() * 4, c->stream));
+  HIPCHK(c, copy_sync(c, c->P, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice)); // (own stream only: see dalloc)
   c->adam_step = 0;
   c->pre_acted = -1;
   refresh_compute_copies(c);
@@ -517,7 +565,7 @@ static int export_flat(aleppo_ctx *c, const float *dev, float *flat, size_t coun
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "export: wrong element count");
   std::vector<float> tmp(c->L.total());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, copy_sync(c, tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
   params_to_reference(c->L, tmp.data(), flat);
   return ALEPPO_OK;
 }
@@ -552,9 +600,9 @@ extern "C" int aleppo_import_optimizer(aleppo_ctx *c, const float *exp_avg, cons
   std::vector<float> tmp(c->L.total());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   params_to_internal(c->L, exp_avg, tmp.data());
-  HIPCHK(c, hipMemcpy(c->M1, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_sync(c, c->M1, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
   params_to_internal(c->L, exp_avg_sq, tmp.data());
-  HIPCHK(c, hipMemcpy(c->M2, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_sync(c, c->M2, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
   c->adam_step = step;
   return ALEPPO_OK;
 }
@@ -619,6 +667,18 @@ static int act_enqueue(aleppo_ctx *c, const float *noise, int slot) {
   const size_t o = (size_t)slot * c->E;
   return do_act(c, noise, slot, rp(c, c->logits_tm, o * c->A), rp(c, c->values_tm, o), c->actions_tm + o, true);
 }
+// The gate's exit condition fired: the stream ran (or will run) a slot whose frames the host never released.
+static int check_gate(aleppo_ctx *c) {
+  const unsigned long long rep = __atomic_load_n(c->h_go + 1, __ATOMIC_ACQUIRE);
+  if (!rep)
+    return ALEPPO_OK;
+  char b[256];
+  std::snprintf(b, sizeof b,
+                "the slot-ahead gate %llu was not released within %.0f ms (released so far: %llu): the device went on "
+                "without the host's frames",
+                rep, (double)c->gate_timeout_ticks / 1e5, __atomic_load_n(c->h_go, __ATOMIC_RELAXED));
+  return fail_ctx(c, ALEPPO_ERR_RUNTIME, b);
+}
 // wait for the ticket the head kernel publishes after the actions (bounded spin, then a real sync)
 // stream_parked: the stream already holds the NEXT slot behind the release word (gated replay) - a stream sync would
 // wait for a release only this thread can give, so the wait only spins (and yields once the slot is clearly a long one)
@@ -637,8 +697,29 @@ static int act_wait(aleppo_ctx *c, long long ticket, bool stream_parked = false)
     if ((++spins & 1023u) == 0) {
       const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (slow) {
-        if (waited > 60.0) // never spin for ever: a slot does not take a minute
-          return set_err(c, ALEPPO_ERR_RUNTIME, "the acting head's ticket did not arrive within 60 s");
+        if (int rc = check_gate(c))
+          return rc;
+        // Backstop only (no hand-off of this design waits on anything but the head kernel in front of it): say what the
+        // stream and the hand-off words look like, so that a missing ticket can be told from a stuck stream.
+        if (waited > 60.0 + (double)c->gate_timeout_ticks / 1e8) {
+          const hipError_t q = hipStreamQuery(c->stream);
+          unsigned int done = 0xFFFFFFFFu; // the head's arrival counter, read on the (idle) side stream
+          if ((c->comm_stream || hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess) &&
+              hipMemcpyAsync(c->h_err + 1, c->d_done, 4, hipMemcpyDeviceToHost, c->comm_stream) == hipSuccess) {
+            for (int i = 0; i < 1000 && hipStreamQuery(c->comm_stream) == hipErrorNotReady; ++i)
+              std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            if (hipStreamQuery(c->comm_stream) == hipSuccess)
+              done = (unsigned int)c->h_err[1];
+          }
+          char b[384];
+          std::snprintf(b, sizeof b,
+                        "the acting head's ticket did not arrive within %.0f s: expected %lld, pinned word %lld, release "
+                        "word %llu, last gate %llu, gate report %llu, head arrival counter %u of %d, stream %s",
+                        waited, ticket, (long long)*tk, __atomic_load_n(c->h_go, __ATOMIC_RELAXED), c->go_seq,
+                        __atomic_load_n(c->h_go + 1, __ATOMIC_RELAXED), done, (c->E + 3) / 4,
+                        q == hipSuccess ? "idle" : q == hipErrorNotReady ? "busy" : hipGetErrorString(q));
+          return fail_ctx(c, ALEPPO_ERR_RUNTIME, b);
+        }
       } else if (waited > 2e-3) {
         if (stream_parked) {
           slow = true;
@@ -650,7 +731,7 @@ static int act_wait(aleppo_ctx *c, long long ticket, bool stream_parked = false)
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  return ALEPPO_OK;
+  return check_gate(c);
 }
 extern "C" int aleppo_act(aleppo_ctx *c, const float *noise, const int64_t **actions_pinned) {
   CHECK_CTX(c);
@@ -829,6 +910,18 @@ extern "C" int aleppo_step(aleppo_ctx *c, const uint8_t *frames, int kind, int l
   c->t++;
   return ALEPPO_OK;
 }
+// Park the main stream: everything enqueued after this runs once the host has stored a number >= the returned sequence
+// number into the release word (gate_kernel; it gives up after gate_timeout_ticks and reports, see check_gate).
+static int gate_enqueue(aleppo_ctx *c) {
+  unsigned long long *go_dev = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&go_dev), c->h_go, 0));
+  launch_gate(c->stream, go_dev, c->go_seq + 1, c->gate_timeout_ticks);
+  HIPCHK(c, hipGetLastError());
+  c->go_seq++; // (only once the gate is on the stream: an error above leaves nothing to release)
+  return ALEPPO_OK;
+}
+static inline void gate_release(aleppo_ctx *c) { __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE); }
+
 // Live loops one slot ahead (the replay loop below does the same with a recorded trace): see include/aleppo.h.
 extern "C" int aleppo_arm_step(aleppo_ctx *c, const uint8_t *frames, int kind, const uint8_t *episode_start_mapped,
                                const float *noise_next) {
@@ -849,25 +942,21 @@ extern "C" int aleppo_arm_step(aleppo_ctx *c, const uint8_t *frames, int kind, c
   if (hipHostGetDevicePointer(&sdev, const_cast<uint8_t *>(episode_start_mapped), 0) != hipSuccess || !sdev)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT,
                    "episode_start_mapped must lie in mapped page-locked host memory (aleppo_host_alloc)");
-  uint32_t *go_dev = nullptr;
-  HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&go_dev), c->h_go, 0));
-  c->go_seq++;
-  hipError_t e = hipStreamWaitValue32(c->stream, go_dev, c->go_seq, hipStreamWaitValueGte, 0xFFFFFFFFu);
-  if (e != hipSuccess) {
-    c->go_seq--;
-    HIPCHK(c, e);
-  }
+  rc = gate_enqueue(c);
+  if (rc)
+    return rc;
   rc = step_enqueue(c, df, kind, ALEPPO_HOST_MAPPED, nullptr, episode_start_mapped, c->t);
   if (rc == ALEPPO_OK && c->t + 1 < c->T) {
     rc = act_enqueue(c, noise_next, c->t + 1);
     c->act_queued_slot = c->t + 1;
     c->act_queued_ticket = c->ticket;
   }
-  if (rc || hipGetLastError() != hipSuccess) { // never leave the stream parked on the release word
-    __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
-    hipStreamSynchronize(c->stream);
-    c->act_queued_slot = -1;
-    return rc ? rc : set_err(c, ALEPPO_ERR_HIP, "aleppo_arm_step: launch failed");
+  if (rc || hipGetLastError() != hipSuccess) {
+    // part of the slot is on the stream behind the gate and must not run on frames that do not exist yet: the context
+    // is failed (sticky), the gate released so that the stream drains (the caller's buffers stay referenced until
+    // aleppo_destroy)
+    const std::string why = rc ? c->err : std::string("a launch failed");
+    return fail_ctx(c, rc ? rc : ALEPPO_ERR_HIP, "aleppo_arm_step: " + why);
   }
   c->armed = true;
   c->armed_start = episode_start_mapped;
@@ -878,12 +967,14 @@ extern "C" int aleppo_release_step(aleppo_ctx *c, const float *rewards, const ui
   CHECK_CTX_ANY(c);
   if (!c->armed)
     return set_err(c, ALEPPO_ERR_RUNTIME, "aleppo_release_step without an armed step");
+  if (!rewards || !terminated || !truncated) // (checked while still armed: the caller can repeat the call)
+    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_gate(c)) // the gate gave up before this release: the slot already ran without the frames
+    return rc;
   // the frames and the episode-start bytes are in place: let the stream go FIRST, the bookkeeping is off its path
   std::atomic_thread_fence(std::memory_order_release);
-  __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
+  gate_release(c);
   c->armed = false;
-  if (!rewards || !terminated || !truncated)
-    return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
   const int E = c->E;
   uint8_t *rec = c->h_rec + (size_t)c->t * c->step_rec_bytes; // uploaded at finish_rollout
   std::memcpy(rec, rewards, (size_t)E * 4);
@@ -906,7 +997,7 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
   const size_t E = (size_t)c->E;
   // rollout.cc:198-278 with the emulator replaced by the recorded trace.  The stream runs ONE slot ahead of the host:
   // slot t + 1's kernels (ingest of the frames the emulator produces from action t, convolutions, fc, head) are enqueued
-  // while slot t is still on the GPU, behind a hipStreamWaitValue32 on a pinned word that the host writes once it HAS
+  // while slot t is still on the GPU, behind a gate (gate_kernel) on a pinned word that the host writes once it HAS
   // slot t's actions (and, with a live emulator, the frames).  The hand-off keeps its order - the GPU never touches slot
   // t + 1's frames before the host has seen action t - but the next slot starts ~1 us after the host's store instead of
   // a kernel-launch latency after it (micro-benchmark tests/tools/waitvalue.hip: 3.7 vs 6.7 us per ping-pong).
@@ -916,24 +1007,15 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
   }();
   const bool gated = gated_env && !c->prof_on && !c->dbg_no_publish;
   auto noise_at = [&](int t) { return noise ? noise + (size_t)t * E * c->A : nullptr; };
-  auto release_all = [&]() { // (error paths: never leave the stream parked on the flag)
-    __atomic_store_n(c->h_go, c->go_seq, __ATOMIC_RELEASE);
-  };
   int rc = act_enqueue(c, noise_at(0), 0);
   if (rc)
     return rc;
   for (int t = 0; t < c->T; ++t) {
     const long long ticket_t = c->ticket; // of act(t), enqueued above / in the previous iteration
     if (gated) {
-      uint32_t *go_dev = nullptr;
-      HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&go_dev), c->h_go, 0));
-      c->go_seq++;
-      const hipError_t e = hipStreamWaitValue32(c->stream, go_dev, c->go_seq, hipStreamWaitValueGte, 0xFFFFFFFFu);
-      if (e != hipSuccess) {
-        c->go_seq--;
-        release_all();
-        HIPCHK(c, e);
-      }
+      rc = gate_enqueue(c); // (nothing of this slot is behind a gate yet: an ordinary error)
+      if (rc)
+        return rc;
     } else {
       rc = act_wait(c, ticket_t);
       if (rc)
@@ -944,15 +1026,12 @@ extern "C" int aleppo_replay_rollout(aleppo_ctx *c, const uint8_t *frames, int k
     if (rc == ALEPPO_OK && t + 1 < c->T)
       rc = act_enqueue(c, noise_at(t + 1), t + 1);
     if (gated) {
-      if (rc) {
-        release_all();
-        hipStreamSynchronize(c->stream);
-        return rc;
-      }
+      if (rc) // a slot is half enqueued behind the gate: see aleppo_arm_step
+        return fail_ctx(c, rc, "aleppo_replay_rollout: " + c->err);
       rc = act_wait(c, ticket_t, /*stream_parked=*/true); // the host has slot t's actions: the emulator would step now
-      release_all();              // ... and hand over slot t + 1's frames
       if (rc)
-        return rc;
+        return c->failed ? rc : fail_ctx(c, rc, "aleppo_replay_rollout: " + c->err);
+      gate_release(c);            // ... and hand over slot t + 1's frames
     } else if (rc) {
       return rc;
     }
@@ -981,7 +1060,7 @@ extern "C" int aleppo_set_gray_lut(aleppo_ctx *c, const uint8_t *lut256) {
   if (!lut256)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "null lut");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->lut, lut256, 256, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_sync(c, c->lut, lut256, 256, hipMemcpyHostToDevice));
   return ALEPPO_OK;
 }
 
@@ -990,6 +1069,8 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   c->act_queued_slot = -1;
   if (c->t != c->T)
     return set_err(c, ALEPPO_ERR_RUNTIME, "Buffer is not full, cannot compute GAE."); // buffer.cc:64-65
+  if (int rcg = check_gate(c))
+    return rcg;
   const int E = c->E, T = c->T, A = c->A;
   // extra selector call on the post-rollout observation: its values bootstrap slot T-1, its sample is
   // discarded but advances the RNG stream like the reference (rollout.cc:268-270)
@@ -1012,6 +1093,8 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
   }
   HIPCHK(c, hipMemcpyAsync(c->h_err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rcg = check_gate(c)) // (the last armed slot's gate may have given up while the stream drained)
+    return rcg;
   c->t = 0;
   c->pre_acted = -1;
   c->need_carry = true;
@@ -1026,28 +1109,22 @@ extern "C" int aleppo_finish_rollout(aleppo_ctx *c, const float *noise) {
 static int ensure_metric_storage(aleppo_ctx *c, int epochs, int M, long B) {
   const size_t need = (size_t)epochs * M * B;
   if (need > c->metric_cap) {
-    if (c->metric_ps)
-      hipFree(c->metric_ps);
+    retire(c, c->metric_ps); // (never hipFree before aleppo_destroy: see dalloc)
     c->metric_ps = nullptr;
-    HIPCHK(c, dalloc(&c->metric_ps, need * 5 * 4));
+    HIPCHK(c, dalloc(&c->metric_ps, need * 5 * 4, c->stream));
     c->metric_cap = need;
   }
   const size_t nm = (size_t)epochs * M;
   if (nm > c->metric_red_cap) {
-    if (c->metric_red)
-      hipFree(c->metric_red);
-    if (c->grad_norms)
-      hipFree(c->grad_norms);
-    if (c->h_metric_red)
-      hipHostFree(c->h_metric_red);
-    if (c->adam_sched)
-      hipFree(c->adam_sched);
-    if (c->h_adam_sched)
-      hipHostFree(c->h_adam_sched);
+    retire(c, c->metric_red);
+    retire(c, c->grad_norms);
+    retire(c, c->adam_sched);
+    retire_host(c, c->h_metric_red);
+    retire_host(c, c->h_adam_sched);
     c->metric_red = c->grad_norms = c->h_metric_red = c->adam_sched = c->h_adam_sched = nullptr;
-    HIPCHK(c, dalloc(&c->metric_red, nm * 8 * 4));
-    HIPCHK(c, dalloc(&c->grad_norms, nm * 4));
-    HIPCHK(c, dalloc(&c->adam_sched, nm * 2 * 4));
+    HIPCHK(c, dalloc(&c->metric_red, nm * 8 * 4, c->stream));
+    HIPCHK(c, dalloc(&c->grad_norms, nm * 4, c->stream));
+    HIPCHK(c, dalloc(&c->adam_sched, nm * 2 * 4, c->stream));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_metric_red), nm * 9 * 4, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_adam_sched), nm * 2 * 4, hipHostMallocDefault));
     c->metric_red_cap = nm;
@@ -1075,6 +1152,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   int rc = ensure_metric_storage(c, epochs, M, B);
   if (rc)
     return rc;
+  for (hipStream_t *st : {&c->wg_stream, &c->comm_stream}) // created on first use: see aleppo_create
+    if (!*st)
+      HIPCHK(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
   ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_comm);
   const bool dp = c->world > 1 || (c->nccl_comm && c->force_comm); // force_comm: 1-rank communicator (tests)
   const int H = c->H, A = c->A, prec = c->prec;
@@ -1297,22 +1377,30 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     rc = enqueue_update();
     hipGraph_t g = nullptr;
-    const hipError_t ee = hipStreamEndCapture(s, &g); // (also ends a capture that failed half way)
-    if (rc) {
+    hipError_t ee = hipStreamEndCapture(s, &g); // (also ends a capture that failed half way)
+    if (rc == ALEPPO_OK && ee == hipSuccess)
+      ee = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+    if (rc || ee != hipSuccess) {
+      // Nothing has run yet (a capture only records).  Drop the half-built graph and its keys so that the next call
+      // starts from the eager path again instead of re-capturing for ever, and report.
       if (g)
         hipGraphDestroy(g);
-      return rc;
+      c->graph_exec = nullptr;
+      c->graph_key = Ctx::GraphKey();
+      c->warm_key = Ctx::GraphKey();
+      if (rc)
+        return rc;
+      HIPCHK(c, ee);
     }
-    HIPCHK(c, ee);
     c->graph = g;
-    HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
     c->graph_key = key;
     HIPCHK(c, hipGraphLaunch(c->graph_exec, s));
     c->graph_replays++;
   } else {
     rc = enqueue_update();
-    if (rc)
-      return rc;
+    if (rc) // some optimizer steps may already be on the stream: parameters / Adam state are no longer what the caller
+            // thinks they are, and adam_step cannot say how far the device got
+      return fail_ctx(c, rc, "aleppo_train failed while enqueuing the update (" + c->err + ")");
     c->warm_key = key;
   }
   c->adam_step += nm;
@@ -1345,7 +1433,7 @@ extern "C" int aleppo_read_train_metric(aleppo_ctx *c, int field, float *dst, si
   if (!dst || field < 0 || field > 4 || count != n || n == 0)
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_train_metric: bad field or count");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(dst, c->metric_ps + (size_t)field * c->metric_cap, n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, copy_sync(c, dst, c->metric_ps + (size_t)field * c->metric_cap, n * 4, hipMemcpyDeviceToHost));
   return ALEPPO_OK;
 }
 
@@ -1353,14 +1441,13 @@ extern "C" int aleppo_read_train_metric(aleppo_ctx *c, int field, float *dst, si
 static int stage_observations(aleppo_ctx *c, const uint8_t *observations, int64_t n) {
   const size_t bytes = (size_t)n * 4 * FRAME_PIX;
   if (bytes > c->stage_u8_cap) {
-    if (c->stage_u8)
-      HIPCHK(c, hipFree(c->stage_u8));
+    retire(c, c->stage_u8);
     c->stage_u8 = nullptr;
     c->stage_u8_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->stage_u8), bytes));
     c->stage_u8_cap = bytes;
   }
-  HIPCHK(c, hipMemcpy(c->stage_u8, observations, bytes, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_sync(c, c->stage_u8, observations, bytes, hipMemcpyHostToDevice));
   return ALEPPO_OK;
 }
 
@@ -1384,11 +1471,11 @@ extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, cons
   if (rc)
     return rc;
   launch_obs_pack(c->stream, c->stage_u8, c->obs, n, train_map(c, 0));
-  HIPCHK(c, hipMemcpy(c->act_n, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_sync(c, c->act_n, a32.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   if (!c->rt16) {
-    HIPCHK(c, hipMemcpy(c->oldlp_n, log_probabilities, (size_t)n * c->A * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->adv_n, advantages, (size_t)n * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->ret_n, returns, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->oldlp_n, log_probabilities, (size_t)n * c->A * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->adv_n, advantages, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->ret_n, returns, (size_t)n * 4, hipMemcpyHostToDevice));
   } else { // half planes: upload as float into the (idle) metric scratch area, round on the device
     rc = ensure_metric_storage(c, 1, 1, (long)n * std::max(c->A, 1));
     if (rc)
@@ -1399,12 +1486,12 @@ extern "C" int aleppo_set_batch(aleppo_ctx *c, const uint8_t *observations, cons
       size_t cnt;
     } pl[3] = {{log_probabilities, c->oldlp_n, (size_t)n * c->A}, {advantages, c->adv_n, (size_t)n}, {returns, c->ret_n, (size_t)n}};
     for (const auto &q : pl) {
-      HIPCHK(c, hipMemcpy(c->metric_ps, q.src, q.cnt * 4, hipMemcpyHostToDevice));
+      HIPCHK(c, copy_sync(c, c->metric_ps, q.src, q.cnt * 4, hipMemcpyHostToDevice));
       launch_plane_from_float(c->stream, c->metric_ps, q.dst, (long)q.cnt, true);
       HIPCHK(c, hipStreamSynchronize(c->stream));
     }
   }
-  HIPCHK(c, hipMemcpy(c->mask_n, masks, (size_t)n, hipMemcpyHostToDevice));
+  HIPCHK(c, copy_sync(c, c->mask_n, masks, (size_t)n, hipMemcpyHostToDevice));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->batch_n = n;
   return ALEPPO_OK;
@@ -1424,8 +1511,7 @@ extern "C" int aleppo_forward(aleppo_ctx *c, const uint8_t *observations, int64_
   // the packed stacks go to a staging area of their own: the rollout's observation slots are not touched
   const size_t need = (size_t)n * FRAME_PIX * 4;
   if (need > c->stage_obs_cap) {
-    if (c->stage_obs)
-      HIPCHK(c, hipFree(c->stage_obs));
+    retire(c, c->stage_obs);
     c->stage_obs = nullptr;
     c->stage_obs_cap = 0;
     HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->stage_obs), need));
@@ -1450,25 +1536,30 @@ extern "C" int aleppo_read_batch(aleppo_ctx *c, int field, void *dst, size_t byt
   const size_t N = (size_t)c->N;
   hipStream_t s = c->stream;
   size_t need = 0;
+  // device scratch owned by the context, grown on demand and never freed before aleppo_destroy (hipFree would wait for
+  // every stream of the device, other contexts' parked ones included: see dalloc)
+  auto scratch = [&](int k, size_t nbytes, void **out) -> int {
+    if (nbytes > c->rb_cap[k]) {
+      retire(c, c->rb_tmp[k]);
+      c->rb_tmp[k] = nullptr;
+      c->rb_cap[k] = 0;
+      HIPCHK(c, hipMalloc(&c->rb_tmp[k], nbytes));
+      c->rb_cap[k] = nbytes;
+    }
+    *out = c->rb_tmp[k];
+    return ALEPPO_OK;
+  };
   void *tmp = nullptr;
   auto fin = [&](const void *src) -> int {
-    if (bytes != need) {
-      if (tmp)
-        hipFree(tmp);
+    if (bytes != need)
       return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: wrong byte count");
-    }
-    hipError_t e = hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess)
-      e = hipStreamSynchronize(s);
-    if (tmp)
-      hipFree(tmp);
-    if (e != hipSuccess)
-      return set_err(c, ALEPPO_ERR_HIP, hipGetErrorString(e));
+    HIPCHK(c, copy_sync(c, dst, src, need, hipMemcpyDeviceToHost));
     return ALEPPO_OK;
   };
   auto transposed = [&](const void *src, size_t pitch, int inner, int elem) -> int {
     need = N * inner * elem;
-    HIPCHK(c, hipMalloc(&tmp, need));
+    if (int rc = scratch(0, need, &tmp))
+      return rc;
     launch_transpose_tm_pitched(s, src, pitch, tmp, E, T, inner, elem);
     return fin(tmp);
   };
@@ -1479,29 +1570,30 @@ extern "C" int aleppo_read_batch(aleppo_ctx *c, int field, void *dst, size_t byt
       return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: wrong byte count");
     if (!c->rt16 && !tm)
       return fin(src);
-    void *em = nullptr;
-    HIPCHK(c, hipMalloc(&tmp, need));
+    if (int rc = scratch(0, need, &tmp))
+      return rc;
     if (tm) {
-      HIPCHK(c, hipMalloc(&em, count * c->rsz));
+      void *em = nullptr;
+      if (int rc = scratch(1, count * c->rsz, &em))
+        return rc;
       launch_transpose_tm_pitched(s, src, (size_t)E * inner * c->rsz, em, E, T, inner, (int)c->rsz);
       src = em;
     }
     launch_plane_to_float(s, src, static_cast<float *>(tmp), (long)count, c->rt16);
-    const int rc2 = fin(tmp);
-    if (em)
-      hipFree(em);
-    return rc2;
+    return fin(tmp);
   };
   switch (field) {
   case ALEPPO_F_OBSERVATIONS: {
     need = N * 4 * FRAME_PIX;
-    HIPCHK(c, hipMalloc(&tmp, need));
+    if (int rc = scratch(0, need, &tmp))
+      return rc;
     launch_obs_unpack(s, c->obs, static_cast<uint8_t *>(tmp), (long)N, train_map(c, 0));
     return fin(tmp);
   }
   case ALEPPO_F_CURRENT_OBS: {
     need = (size_t)E * 4 * FRAME_PIX;
-    HIPCHK(c, hipMalloc(&tmp, need));
+    if (int rc = scratch(0, need, &tmp))
+      return rc;
     const int slot = (c->t == 0 && c->need_carry) ? T : c->t;
     launch_obs_unpack(s, c->obs, static_cast<uint8_t *>(tmp), E, slot_map(c, slot));
     return fin(tmp);
@@ -1511,8 +1603,7 @@ extern "C" int aleppo_read_batch(aleppo_ctx *c, int field, void *dst, size_t byt
     if (bytes != need)
       return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "read_batch: wrong byte count");
     std::vector<int> a(N);
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipMemcpy(a.data(), c->act_n, N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, copy_sync(c, a.data(), c->act_n, N * 4, hipMemcpyDeviceToHost));
     int64_t *o = static_cast<int64_t *>(dst);
     for (size_t i = 0; i < N; ++i)
       o[i] = a[i];
@@ -1592,6 +1683,8 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->force_comm = value != 0;
   else if (option == ALEPPO_OPT_UPDATE_GRAPH)
     c->update_graph = value != 0;
+  else if (option == ALEPPO_OPT_GATE_TIMEOUT_MS)
+    c->gate_timeout_ticks = (unsigned long long)std::max(1, value) * 100000ull; // 100 MHz wall clock
   else
     return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
   return ALEPPO_OK;
@@ -1610,6 +1703,7 @@ extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
   case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
   case ALEPPO_OPT_FUSE_C2D_C1W: *value = c->tune.fuse_c2d_c1w; break;
   case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
+  case ALEPPO_OPT_GATE_TIMEOUT_MS: *value = (int64_t)(c->gate_timeout_ticks / 100000ull); break;
   default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
   }
   return ALEPPO_OK;
@@ -1644,20 +1738,72 @@ extern "C" int aleppo_profile_read(aleppo_ctx *c, int cls, double *avg_ms, int64
 }
 
 // ------------------------------------------------------------------ stateless operators
+// Device memory and the stream of the stateless operators: a process-wide arena per device, grown in chunks that are
+// never freed, and a non-blocking stream of its own.  (hipFree, hipDeviceSynchronize and null-stream work would wait for,
+// or order themselves against, every other stream of the device - a context's stream parked behind its release word
+// included)  One operator call at a time per device (mutex); a call's buffers live until it returns.
 namespace {
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() {
-    if (p)
-      hipFree(p);
+struct OpArena {
+  std::mutex mu;
+  hipStream_t st = nullptr;
+  struct Chunk {
+    char *p;
+    size_t cap, used;
+  };
+  std::vector<Chunk> chunks;
+};
+OpArena &op_arena(int dev) {
+  static OpArena a[64];
+  return a[dev & 63];
+}
+struct OpScope;
+thread_local OpScope *g_op = nullptr;
+struct OpScope {
+  OpArena &ar;
+  std::unique_lock<std::mutex> lk;
+  hipStream_t st = nullptr;
+  hipError_t err = hipSuccess;
+  explicit OpScope(int dev) : ar(op_arena(dev)), lk(ar.mu) {
+    if (!ar.st)
+      err = hipStreamCreateWithFlags(&ar.st, hipStreamNonBlocking);
+    st = ar.st;
+    for (auto &ch : ar.chunks)
+      ch.used = 0;
+    g_op = this;
   }
+  ~OpScope() { g_op = nullptr; }
+  hipError_t alloc(void **out, size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
+    for (auto &ch : ar.chunks)
+      if (ch.cap - ch.used >= bytes) {
+        *out = ch.p + ch.used;
+        ch.used += bytes;
+        return hipSuccess;
+      }
+    OpArena::Chunk ch{nullptr, std::max<size_t>(bytes, (size_t)32 << 20), bytes};
+    const hipError_t e = hipMalloc(reinterpret_cast<void **>(&ch.p), ch.cap);
+    if (e != hipSuccess)
+      return e;
+    ar.chunks.push_back(ch);
+    *out = ch.p;
+    return hipSuccess;
+  }
+  hipError_t sync() { return hipStreamSynchronize(st); }
+  hipError_t down(void *dst, const void *src, size_t bytes) { // device -> host, complete on return
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    return e == hipSuccess ? sync() : e;
+  }
+};
+struct DevBuf { // a buffer of the current operator call (arena memory: nothing to free)
+  void *p = nullptr;
   hipError_t up(const void *src, size_t bytes) {
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    hipError_t e = g_op->alloc(&p, bytes);
     if (e == hipSuccess && src)
-      e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+      e = hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, g_op->st);
     else if (e == hipSuccess)
-      e = hipMemset(p, 0, bytes ? bytes : 16);
-    return e;
+      e = hipMemsetAsync(p, 0, bytes ? bytes : 16, g_op->st);
+    // (pageable host sources are staged before the call returns; waiting here keeps the caller's buffer rule simple)
+    return e == hipSuccess ? g_op->sync() : e;
   }
   template <class T> T *as() { return static_cast<T *>(p); }
 };
@@ -1683,6 +1829,8 @@ extern "C" int aleppo_gae(int dev, float *advantages, const float *rewards, cons
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   const size_t n = (size_t)E * T, rb = ((size_t)7 * E + 15) / 16 * 16;
   std::vector<uint8_t> rec(rb * T, 0);
   std::vector<float> vtm((size_t)(T + 1) * E);
@@ -1705,14 +1853,14 @@ extern "C" int aleppo_gae(int dev, float *advantages, const float *rewards, cons
   OPCHK(r.up(nullptr, n * 4));
   OPCHK(m.up(nullptr, n));
   OPCHK(er.up(nullptr, 16));
-  launch_gae(nullptr, drec.as<uint8_t>(), rb, dv.as<float>(), nullptr, nullptr, a.as<float>(), r.as<float>(), nullptr,
+  launch_gae(op.st, drec.as<uint8_t>(), rb, dv.as<float>(), nullptr, nullptr, a.as<float>(), r.as<float>(), nullptr,
              nullptr, m.as<uint8_t>(), er.as<int>(), (int)E, (int)T, 0, gamma, lambda, /*clamp=*/false);
   int err = 0;
-  OPCHK(hipMemcpy(&err, er.p, 4, hipMemcpyDeviceToHost));
+  OPCHK(op.down(&err, er.p, 4));
   if (err)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT,
                    "Episode starts, terminals, and truncations must be mutually exclusive."); // gae.cc:49-53
-  OPCHK(hipMemcpy(advantages, a.p, n * 4, hipMemcpyDeviceToHost));
+  OPCHK(op.down(advantages, a.p, n * 4));
   return ALEPPO_OK;
 }
 
@@ -1722,11 +1870,13 @@ extern "C" int aleppo_vision_resize_area(int dev, const float *images, float *ou
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   DevBuf i, o;
   OPCHK(i.up(images, (size_t)n * RAW_H * RAW_W * 4));
   OPCHK(o.up(nullptr, (size_t)n * FRAME_PIX * 4));
-  launch_area_resize(nullptr, i.as<float>(), o.as<float>(), n);
-  OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX * 4, hipMemcpyDeviceToHost));
+  launch_area_resize(op.st, i.as<float>(), o.as<float>(), n);
+  OPCHK(op.down(out, o.p, (size_t)n * FRAME_PIX * 4));
   return ALEPPO_OK;
 }
 extern "C" int aleppo_vision_rgb_to_gray(int dev, const float *images, float *out, int64_t n) {
@@ -1735,11 +1885,13 @@ extern "C" int aleppo_vision_rgb_to_gray(int dev, const float *images, float *ou
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   DevBuf i, o;
   OPCHK(i.up(images, (size_t)n * 3 * FRAME_PIX * 4));
   OPCHK(o.up(nullptr, (size_t)n * FRAME_PIX * 4));
-  launch_rgb_to_gray(nullptr, i.as<float>(), o.as<float>(), n);
-  OPCHK(hipMemcpy(out, o.p, (size_t)n * FRAME_PIX * 4, hipMemcpyDeviceToHost));
+  launch_rgb_to_gray(op.st, i.as<float>(), o.as<float>(), n);
+  OPCHK(op.down(out, o.p, (size_t)n * FRAME_PIX * 4));
   return ALEPPO_OK;
 }
 
@@ -1749,6 +1901,7 @@ static int ingest_op(bool raw, const uint8_t *frames, size_t frame_bytes, const 
                      const uint8_t *obs_nchw_in, const uint8_t *start, uint8_t *obs_nchw_out, int64_t n) {
   if (n > MAX_ENVS_PER_RANK)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "at most 8192 environments per call");
+  OpScope &op = *g_op; // opened by the caller
   DevBuf f, l, st, nchw, slots;
   OPCHK(f.up(frames, frame_bytes));
   uint8_t ident[256];
@@ -1763,12 +1916,12 @@ static int ingest_op(bool raw, const uint8_t *frames, size_t frame_bytes, const 
   OPCHK(st.up(start, (size_t)n));
   OPCHK(nchw.up(obs_nchw_in, (size_t)n * 4 * FRAME_PIX)); // (zeros when there is no previous stack)
   OPCHK(slots.up(nullptr, (size_t)n * 2 * FRAME_PIX * 4));
-  launch_obs_pack(nullptr, nchw.as<uint8_t>(), slots.as<uint32_t>(), n, SampleMap{1, 2L * FRAME_PIX, 0, 0, 0});
-  launch_ingest(nullptr, raw, f.as<uint8_t>(), l.as<uint8_t>(), st.as<uint8_t>(), nullptr, slots.as<uint32_t>(), (int)n,
+  launch_obs_pack(op.st, nchw.as<uint8_t>(), slots.as<uint32_t>(), n, SampleMap{1, 2L * FRAME_PIX, 0, 0, 0});
+  launch_ingest(op.st, raw, f.as<uint8_t>(), l.as<uint8_t>(), st.as<uint8_t>(), nullptr, slots.as<uint32_t>(), (int)n,
                 2, 0, 1);
-  launch_obs_unpack(nullptr, slots.as<uint32_t>(), nchw.as<uint8_t>(), n, SampleMap{1, 2L * FRAME_PIX, 0, FRAME_PIX, 0});
-  OPCHK(hipDeviceSynchronize());
-  OPCHK(hipMemcpy(obs_nchw_out, nchw.p, (size_t)n * 4 * FRAME_PIX, hipMemcpyDeviceToHost));
+  launch_obs_unpack(op.st, slots.as<uint32_t>(), nchw.as<uint8_t>(), n, SampleMap{1, 2L * FRAME_PIX, 0, FRAME_PIX, 0});
+  OPCHK(op.sync());
+  OPCHK(op.down(obs_nchw_out, nchw.p, (size_t)n * 4 * FRAME_PIX));
   return ALEPPO_OK;
 }
 extern "C" int aleppo_preprocess(int dev, const uint8_t *raw_pairs, const uint8_t *lut256, uint8_t *out, int64_t n) {
@@ -1777,6 +1930,8 @@ extern "C" int aleppo_preprocess(int dev, const uint8_t *raw_pairs, const uint8_
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   // every environment in an episode-start slot: the new frame is broadcast to all four stack planes; plane 0 is it
   std::vector<uint8_t> stack((size_t)n * 4 * FRAME_PIX);
   rc = ingest_op(true, raw_pairs, (size_t)n * 2 * RAW_H * RAW_W, lut256, nullptr, nullptr, stack.data(), n);
@@ -1793,6 +1948,8 @@ extern "C" int aleppo_update_observations(int dev, uint8_t *observations, const 
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   return ingest_op(false, frames, (size_t)E * FRAME_PIX, nullptr, observations, episode_start, observations, E);
 }
 
@@ -1817,6 +1974,8 @@ extern "C" int aleppo_ppo_loss(int dev, const float *logits, const float *old_lp
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   constexpr int H = 32; // >= MAX_ACTIONS + 1
   std::vector<float> h((size_t)B * H, 0.f), Wh((size_t)(A + 1) * H, 0.f), bh((size_t)A + 1, 0.f);
   for (int64_t i = 0; i < B; ++i) {
@@ -1842,25 +2001,25 @@ extern "C" int aleppo_ppo_loss(int dev, const float *logits, const float *old_lp
   OPCHK(sw.up(nullptr, (size_t)nblk * (A + 1) * H * 4));
   OPCHK(sb.up(nullptr, (size_t)nblk * (A + 1) * 4));
   OPCHK(red.up(nullptr, 8 * 4));
-  launch_mask_count(nullptr, ma.as<uint8_t>(), cnt.as<float>(), B, 1); // losses.cc:19 masks.sum()
+  launch_mask_count(op.st, ma.as<uint8_t>(), cnt.as<float>(), B, 1); // losses.cc:19 masks.sum()
   float *p = ps.as<float>();
-  launch_head_train(nullptr, dh_in.as<float>(), dW.as<float>(), db.as<float>(), ac.as<int>(), ol.as<float>(),
+  launch_head_train(op.st, dh_in.as<float>(), dW.as<float>(), db.as<float>(), ac.as<int>(), ol.as<float>(),
                     ad.as<float>(), re.as<float>(), ma.as<uint8_t>(), cnt.as<float>(), Hyper{clip, c_v, c_e, 0.f},
                     dh_out.p, ALEPPO_FP32, p, p + B, p + 2 * B, p + 3 * B, p + 4 * B, sw.as<float>(), sb.as<float>(),
                     nblk, B, H, (int)A, nullptr, nullptr, 1, nullptr);
-  launch_metrics_reduce(nullptr, p, (size_t)B, ma.as<uint8_t>(), B, 1, 1, red.as<float>());
-  OPCHK(hipDeviceSynchronize());
+  launch_metrics_reduce(op.st, p, (size_t)B, ma.as<uint8_t>(), B, 1, 1, red.as<float>());
+  OPCHK(op.sync());
   float r8[8];
-  OPCHK(hipMemcpy(r8, red.p, sizeof(r8), hipMemcpyDeviceToHost));
+  OPCHK(op.down(r8, red.p, sizeof(r8)));
   if (loss)
     *loss = r8[0] / r8[5];
   float *per[5] = {total_losses, clipped, value_losses, entropies, ratio}; // order of the kernel's metric planes
   for (int k = 0; k < 5; ++k)
     if (per[k])
-      OPCHK(hipMemcpy(per[k], p + (size_t)k * B, (size_t)B * 4, hipMemcpyDeviceToHost));
+      OPCHK(op.down(per[k], p + (size_t)k * B, (size_t)B * 4));
   if (dlogits || dvalues) {
     std::vector<float> d((size_t)B * H);
-    OPCHK(hipMemcpy(d.data(), dh_out.p, d.size() * 4, hipMemcpyDeviceToHost));
+    OPCHK(op.down(d.data(), dh_out.p, d.size() * 4));
     for (int64_t i = 0; i < B; ++i) {
       if (dlogits)
         for (int64_t k = 0; k < A; ++k)
@@ -1879,14 +2038,16 @@ extern "C" int aleppo_sample(int dev, const float *probs, const float *q, int64_
   int rc = select_device(dev);
   if (rc)
     return rc;
+  OpScope op(dev);
+  OPCHK(op.err);
   DevBuf p, qq, a;
   OPCHK(p.up(probs, (size_t)E * A * 4));
   OPCHK(qq.up(q, (size_t)E * A * 4));
   OPCHK(a.up(nullptr, (size_t)E * 4));
-  launch_infer_head(nullptr, nullptr, FC_SPLITS, nullptr, nullptr, nullptr, qq.as<float>(), 0, 0, nullptr, nullptr,
+  launch_infer_head(op.st, nullptr, FC_SPLITS, nullptr, nullptr, nullptr, qq.as<float>(), 0, 0, nullptr, nullptr,
                     a.as<int>(), nullptr, nullptr, 0, (int)E, 32, (int)A, p.as<float>());
   std::vector<int> a32((size_t)E);
-  OPCHK(hipMemcpy(a32.data(), a.p, (size_t)E * 4, hipMemcpyDeviceToHost));
+  OPCHK(op.down(a32.data(), a.p, (size_t)E * 4));
   for (int64_t e = 0; e < E; ++e)
     actions[e] = a32[(size_t)e];
   return ALEPPO_OK;

@@ -102,8 +102,15 @@ struct Ctx {
   int *d_err = nullptr;        // device error word (flag overlap)
   unsigned int *d_done = nullptr; // arrival counter of the head kernel's ticket publish
   long long ticket = 0;        // last ticket published to h_actions[E]
-  uint32_t *h_go = nullptr;    // pinned, GPU-visible: the stream waits on it (hipStreamWaitValue32) before a gated slot
-  uint32_t go_seq = 0;         // last value the stream was told to wait for / the host released
+  // pinned, GPU-visible hand-off words of the slot-ahead gate (gate_kernel): [0] release sequence (host writes),
+  // [1] time-out report (the gate writes the sequence number it gave up on; 0 = none)
+  unsigned long long *h_go = nullptr;
+  unsigned long long go_seq = 0; // last sequence number a gate was enqueued for (64 bits: never wraps)
+  unsigned long long gate_timeout_ticks = 0; // the gate's exit condition, in 100 MHz wall-clock ticks
+  // a failure that leaves the rollout / learner state undefined (a gate that timed out, an update that failed half way):
+  // every later stateful call but aleppo_destroy returns this error again
+  bool failed = false;
+  std::string fail_msg;
   unsigned noise_flip = 0;
   // aleppo_arm_step / aleppo_release_step: a step (and the next slot's acting kernels) enqueued behind the release word
   bool armed = false;
@@ -173,7 +180,12 @@ struct Ctx {
   // ---- profiling ----
   Tuning tune;
   hipError_t async_err = hipSuccess; // first failure of a call whose status could not be returned on the spot
-  // ---- boundary staging (aleppo_set_batch / aleppo_forward): grown on demand, freed in aleppo_destroy
+  // ---- boundary staging (aleppo_set_batch / aleppo_forward / aleppo_read_batch): grown on demand and never freed before
+  // aleppo_destroy - hipFree / hipHostFree wait for EVERY stream of the device, including another context's stream
+  // parked behind its release word, so no entry point but destroy calls them
+  std::vector<void *> retired, retired_host;
+  void *rb_tmp[2] = {nullptr, nullptr}; // aleppo_read_batch scratch
+  size_t rb_cap[2] = {0, 0};
   uint8_t *stage_u8 = nullptr;   // NCHW uint8 observations as uploaded
   size_t stage_u8_cap = 0;
   uint32_t *stage_obs = nullptr; // packed stacks of aleppo_forward's samples (never the rollout slots)
@@ -201,6 +213,7 @@ struct StartBits { // episode-start flags of one slot as a kernel argument (bit 
 void launch_ingest(hipStream_t s, bool raw, const uint8_t *frames, const uint8_t *lut, const uint8_t *start,
                    const StartBits *sbits, uint32_t *obs, int E, int slots, int t_src, int t_dst);
 void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, int dst);
+void launch_gate(hipStream_t s, unsigned long long *go_dev, unsigned long long seq, unsigned long long timeout_ticks);
 void launch_infer_head(hipStream_t s, const float *hpart, int nsplit, const float *bfc, const float *Wh,
                        const float *bh, const float *noise, uint64_t seed, uint64_t counter, void *logits_t,
                        void *values_t, int *actions_t, int64_t *pinned, unsigned int *done_ctr, long long ticket, int E,

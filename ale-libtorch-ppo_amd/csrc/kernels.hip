@@ -122,6 +122,34 @@ void launch_copy_slot(hipStream_t s, uint32_t *obs, int E, int slots, int src, i
 }
 
 // ================================================================================================
+// The slot-ahead hand-off's gate (rollout.cc:204-208 / :312-313: the next forward pass may only start once the host has
+// the actions and the emulators have delivered the frames).  The next slot's kernels are enqueued BEHIND this one-wave
+// kernel; it returns when the host has stored a sequence number >= seq into the release word (mapped page-locked host
+// memory, read with system-scope loads: every poll is a bus round trip, nothing is cached).
+// Exit condition every wave reaches: after timeout_ticks of the 100 MHz wall clock the kernel gives up, reports the
+// sequence number it was waiting for in go[1] and returns - the stream drains, the host finds the report and fails the
+// context; the GPU never waits for ever on a host that has gone away.
+// (Replaces hipStreamWaitValue32, which this runtime implements as the same kind of polling kernel - but without an
+// exit condition, behind a capability flag, and on a 32-bit word that wraps.)
+// ================================================================================================
+__global__ __launch_bounds__(64) void gate_kernel(unsigned long long *go, unsigned long long seq,
+                                                   unsigned long long timeout_ticks) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(go + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+}
+void launch_gate(hipStream_t s, unsigned long long *go_dev, unsigned long long seq, unsigned long long timeout_ticks) {
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, s, go_dev, seq, timeout_ticks);
+}
+
+// ================================================================================================
 // Action head + categorical sampling (action selector closure, train.cc:367-379): logits / value from
 // the hidden vector, softmax, multinomial(1, replacement) == argmax_k(p_k / q_k), q ~ Exp(1) (Q10),
 // first maximum wins.  One wave per environment.  Actions go to the rollout slot AND to pinned host

@@ -10,7 +10,12 @@
  * Conventions: C linkage, opaque context, plain pointers and sizes, no C++ / torch types.
  * Every call returns ALEPPO_OK (0) or a negative aleppo_status; aleppo_last_error() gives the
  * message (the reference throws std::invalid_argument / std::runtime_error at the same places).
- * One owner thread per context.  Host pointers are caller-owned and may be reused as soon as the
+ * One owner thread per context; several contexts of one process may be driven from different threads at the same time.
+ * After aleppo_create a context only ever touches its own HIP streams: no entry point but aleppo_destroy (and
+ * aleppo_host_free) calls hipFree / hipHostFree / hipDeviceSynchronize or uses the null stream - those wait for every
+ * stream of the device, another context's stream parked behind its release word included (aleppo_arm_step).  The same
+ * rule binds the caller: while a step is armed, its owner thread must be the one that releases it, and no OTHER call of
+ * that thread may wait for the device.  Host pointers are caller-owned and may be reused as soon as the
  * call returns, unless stated.  Tensors crossing the boundary use the REFERENCE's layouts
  * (env-major [E,T,...], NCHW uint8 observations, libtorch parameters() order); internal HBM
  * layouts are private.
@@ -181,12 +186,17 @@ int aleppo_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, int loca
  * aleppo_arm_step - called right after aleppo_act returned slot t's actions, BEFORE the emulators are stepped - enqueues
  * the ingest of the frames the emulators are about to write into `frames` and of the episode-start flags they are about
  * to write into `episode_start_mapped` (uint8 [E]; both in mapped page-locked memory from aleppo_host_alloc), plus slot
- * t+1's acting kernels (noise_next: that slot's sampling noise or NULL), all behind a stream wait
- * (hipStreamWaitValue32) on a release word.  aleppo_release_step - called when the emulators are done - releases the
+ * t+1's acting kernels (noise_next: that slot's sampling noise or NULL), all behind a one-wave gate kernel that polls a
+ * release word in mapped host memory.  aleppo_release_step - called when the emulators are done - releases the
  * stream and records slot t's scalars (the per-env writes of rollout.cc:212-227; episode starts are read from
  * episode_start_mapped); it advances t.  The next aleppo_act only waits for the actions (its noise argument is ignored:
  * that head is already on the stream with noise_next).  Between the two calls every
- * other stateful entry point fails with ALEPPO_ERR_RUNTIME.  Results are bit-identical to aleppo_act / aleppo_step. */
+ * other stateful entry point fails with ALEPPO_ERR_RUNTIME.  Results are bit-identical to aleppo_act / aleppo_step.
+ * The gate has an exit condition: if it is not released within ALEPPO_OPT_GATE_TIMEOUT_MS (default 120 000) it gives
+ * up, the stream drains, and the release (or the next aleppo_act / aleppo_finish_rollout) fails the context: from then
+ * on every call returns ALEPPO_ERR_RUNTIME with that message until aleppo_destroy; the frame buffers must stay
+ * allocated until then.  A null argument to aleppo_release_step is reported while the step is still armed (repeat the
+ * call). */
 int aleppo_arm_step(aleppo_ctx *ctx, const uint8_t *frames, int frame_kind, const uint8_t *episode_start_mapped,
                     const float *noise_next);
 int aleppo_release_step(aleppo_ctx *ctx, const float *rewards, const uint8_t *terminated, const uint8_t *truncated);
@@ -309,6 +319,8 @@ typedef enum {
                                       is faster (default: given 84x84 frames, raw pairs in mapped host memory), 2 always */
   ALEPPO_OPT_FUSE_C2D_C1W = 8,     /* 1: conv2 dgrad + conv1 wgrad as ONE launch, dz1 never reaches HBM (opt-in: less traffic,
                                       faster alone, slower beside the co-scheduled conv2 wgrad) */
+  ALEPPO_OPT_GATE_TIMEOUT_MS = 9,  /* exit condition of the slot-ahead gate in milliseconds (default 120 000; also the
+                                      environment variable ALEPPO_GATE_TIMEOUT_MS at aleppo_create) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */

@@ -32,6 +32,16 @@ __global__ void gate(const unsigned long long *go, unsigned long long seq, unsig
     }
   }
 }
+__global__ void fresh(int *p) {
+  if (threadIdx.x == 1)
+    p[1] = 2;
+}
+__global__ void fresh2(int *p) {
+  extern __shared__ int sm[];
+  sm[threadIdx.x] = 1;
+  if (threadIdx.x == 2)
+    p[2] = sm[3];
+}
 __global__ void noop(int *p) {
   if (p && threadIdx.x == 0)
     *p = 1;
@@ -55,11 +65,26 @@ int main() {
   void *pinned = nullptr;
   CK(hipHostMalloc(&pinned, 1 << 16, hipHostMallocDefault));
 
+  auto new_streams = [&](int n) {
+    std::vector<hipStream_t> v(n);
+    for (auto &t : v)
+      CK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+    for (auto &t : v)
+      hipLaunchKernelGGL(noop, dim3(1), dim3(64), 0, t, dscratch);
+    for (auto &t : v)
+      CK(hipStreamSynchronize(t));
+    for (auto &t : v)
+      CK(hipStreamDestroy(t));
+  };
   struct Probe {
     const char *name;
     std::function<void()> fn;
   };
   void *victim = nullptr, *hvictim = nullptr, *extra = nullptr;
+  std::vector<void *> leak;
+  std::vector<char> bighost(8 << 20);
+  void *big = nullptr;
+  CK(hipMalloc(&big, 8 << 20));
   std::vector<Probe> probes = {
       {"hipFree", [&] { CK(hipFree(victim)); }},
       {"hipHostFree", [&] { CK(hipHostFree(hvictim)); }},
@@ -73,6 +98,25 @@ int main() {
       {"kernel+sync other stream", [&] { hipLaunchKernelGGL(noop, dim3(1), dim3(64), 0, S2, dscratch); CK(hipStreamSynchronize(S2)); }},
       {"hipStreamCreate+Destroy", [&] { hipStream_t t; CK(hipStreamCreateWithFlags(&t, hipStreamNonBlocking)); CK(hipStreamDestroy(t)); }},
       {"hipEventRecord(other)+Synchronize", [&] { CK(hipEventRecord(ev, S2)); CK(hipEventSynchronize(ev)); }},
+      {"hipHostMalloc(default)", [&] { void *q; CK(hipHostMalloc(&q, 1 << 16, hipHostMallocDefault)); leak.push_back(q); }},
+      {"hipHostMalloc(mapped)", [&] { void *q; CK(hipHostMalloc(&q, 1 << 16, hipHostMallocMapped)); leak.push_back(q); }},
+      {"hipHostGetDevicePointer", [&] { void *d; CK(hipHostGetDevicePointer(&d, pinned, 0)); }},
+      {"hipEventCreate+Destroy", [&] { hipEvent_t e; CK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); CK(hipEventDestroy(e)); }},
+      {"hipMemsetAsync+sync other stream", [&] { CK(hipMemsetAsync(dscratch, 0, 1 << 16, S2)); CK(hipStreamSynchronize(S2)); }},
+      {"MemcpyAsync H2D pageable other+sync", [&] { CK(hipMemcpyAsync(dscratch, hostbuf.data(), hostbuf.size(), hipMemcpyHostToDevice, S2)); CK(hipStreamSynchronize(S2)); }},
+      {"MemcpyAsync D2H pageable other+sync", [&] { CK(hipMemcpyAsync(hostbuf.data(), dscratch, hostbuf.size(), hipMemcpyDeviceToHost, S2)); CK(hipStreamSynchronize(S2)); }},
+      {"MemcpyAsync H2D 8MB pageable other", [&] { CK(hipMemcpyAsync(big, bighost.data(), bighost.size(), hipMemcpyHostToDevice, S2)); CK(hipStreamSynchronize(S2)); }},
+      {"MemcpyAsync D2H 8MB pageable other", [&] { CK(hipMemcpyAsync(bighost.data(), big, bighost.size(), hipMemcpyDeviceToHost, S2)); CK(hipStreamSynchronize(S2)); }},
+      {"hipStreamQuery(parked)", [&] { (void)hipStreamQuery(S); }},
+      {"hipGetDeviceProperties+SetDevice", [&] { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); CK(hipSetDevice(0)); }},
+      {"first launch of a new kernel (other)", [&] { hipLaunchKernelGGL(fresh, dim3(1), dim3(64), 0, S2, dscratch); CK(hipStreamSynchronize(S2)); }},
+      {"hipFuncSetAttribute", [&] { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(fresh2), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); }},
+      {"hipMalloc 1 GB", [&] { CK(hipMalloc(&extra, (size_t)1 << 30)); }},
+      // streams created AFTER the gate was parked: the runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4)
+      // hardware queues, and a kernel that lands in the parked stream's queue waits behind the gate
+      {"kernel on 1 new stream", [&] { new_streams(1); }},
+      {"kernels on 3 new streams", [&] { new_streams(3); }},
+      {"kernels on 6 new streams", [&] { new_streams(6); }},
   };
   unsigned long long seq = 0;
   std::printf("%-36s %10s %10s\n", "foreign call", "F [s]", "L [s]");

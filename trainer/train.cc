@@ -713,28 +713,66 @@ int main(int argc, char **argv) {
     check(nullptr, aleppo_create(&ac, &ctx));
     std::cout << "MI355X is available! Training on GPU (rom argument '" << rom_path << "' -> synthetic emulator)."
               << std::endl;
-    if (world > 1) { // RCCL communicator: rank 0's 128-byte id travels through a file next to the log
-      const std::string idfile = std::string(argv[2]) + ".rcclid";
+    if (world > 1) {
+      // RCCL communicator: rank 0's 128-byte id travels through a file next to the log.  The file belongs to ONE launch:
+      // its name carries the launcher's MASTER_PORT (+ torchrun's run id when there is one), rank 0 removes whatever a
+      // crashed earlier launch left under that name BEFORE it creates the id and removes its own file once every rank
+      // has joined (aleppo_comm_init is collective), and the other ranks ignore a file older than their own start: a
+      // stale id would leave ncclCommInitRank waiting for ever on mismatched ids.
+      std::string nonce = std::getenv("MASTER_PORT") ? std::getenv("MASTER_PORT") : "0";
+      if (const char *rid = std::getenv("TORCHELASTIC_RUN_ID"))
+        nonce += std::string(".") + rid;
+      const std::string idfile = std::string(argv[2]) + ".rcclid." + nonce;
+      const auto proc_start = std::filesystem::file_time_type::clock::now();
       uint8_t id[ALEPPO_UNIQUE_ID_BYTES];
       if (rank == 0) {
+        std::error_code ec;
+        std::filesystem::remove(idfile, ec);
+        for (int r = 1; r < world; ++r)
+          std::filesystem::remove(idfile + ".ack." + std::to_string(r), ec);
         check(nullptr, aleppo_comm_unique_id(id));
         {
           std::ofstream f(idfile + ".tmp", std::ios::binary);
           f.write(reinterpret_cast<const char *>(id), sizeof(id));
+          if (!f)
+            throw std::runtime_error("cannot write " + idfile + ".tmp");
         }
-        std::filesystem::rename(idfile + ".tmp", idfile);
+        std::filesystem::rename(idfile + ".tmp", idfile); // atomic: a reader sees all 128 bytes or no file
       } else {
+        const double limit = std::getenv("ALEPPO_RENDEZVOUS_TIMEOUT_S") ? std::atof(std::getenv("ALEPPO_RENDEZVOUS_TIMEOUT_S")) : 300.0;
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
-          std::ifstream f(idfile, std::ios::binary);
-          if (f && f.read(reinterpret_cast<char *>(id), sizeof(id)))
-            break;
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300))
-            throw std::runtime_error("timed out waiting for " + idfile);
+          std::error_code ec;
+          const auto mt = std::filesystem::last_write_time(idfile, ec);
+          // (ranks of one launch start within seconds of each other: anything written more than two minutes before this
+          // process started is a leftover)
+          if (!ec && mt + std::chrono::seconds(120) >= proc_start) {
+            std::ifstream f(idfile, std::ios::binary);
+            if (f && f.read(reinterpret_cast<char *>(id), sizeof(id))) {
+              std::ofstream(idfile + ".ack." + std::to_string(rank)) << "read\n"; // rank 0 keeps the file until then
+              break;
+            }
+          }
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            throw std::runtime_error("rank " + std::to_string(rank) + " timed out after " + std::to_string((int)limit) +
+                                     " s waiting for rank 0's communicator id in " + idfile +
+                                     (ec ? " (no such file)" : " (only a stale file from an earlier launch)"));
           std::this_thread::sleep_for(std::chrono::milliseconds(50));
         }
       }
       check(ctx, aleppo_comm_init(ctx, id));
+      if (rank == 0) { // remove the file once every rank has acknowledged reading it (bounded: a rank that died before
+                       // it read the id has already failed the collective init above, or will fail the first all-reduce)
+        const auto t0 = std::chrono::steady_clock::now();
+        std::error_code ec;
+        for (int r = 1; r < world; ++r) {
+          const std::string ack = idfile + ".ack." + std::to_string(r);
+          while (!std::filesystem::exists(ack, ec) && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(300))
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+          std::filesystem::remove(ack, ec);
+        }
+        std::filesystem::remove(idfile, ec);
+      }
       std::cout << "rank " << rank << " of " << world << ": environments [" << env0 << ", " << env0 + E << ")" << std::endl;
     }
     {
