@@ -56,7 +56,7 @@ EXPORTS = [
     "aleppo_update_observations", "aleppo_ppo_loss", "aleppo_sample", "aleppo_profile_enable", "aleppo_profile_read",
     "aleppo_profile_reset", "aleppo_synchronize", "aleppo_set_option", "aleppo_export_optimizer",
     "aleppo_import_optimizer", "aleppo_replay_rollout", "aleppo_get_option",
-    "aleppo_host_alloc", "aleppo_host_free", "aleppo_arm_step", "aleppo_release_step",
+    "aleppo_host_alloc", "aleppo_host_free", "aleppo_arm_step", "aleppo_release_step", "aleppo_device_check",
 ]
 
 
@@ -110,6 +110,11 @@ def _check(rc, ctx=None):
     if rc == ERR_INVALID_ARGUMENT:
         raise AleppoInvalidArgument(msg)
     raise AleppoError(msg)
+
+
+def device_check(device=0):
+    """aleppo_device_check: raises AleppoError ("no CPU fallback") unless HIP device `device` is a gfx950"""
+    _check(lib().aleppo_device_check(C.c_int(device)))
 
 
 def _f32(a):

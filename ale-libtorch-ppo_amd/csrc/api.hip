@@ -312,6 +312,8 @@ static int select_device(int ordinal) {
   return ALEPPO_OK;
 }
 
+extern "C" int aleppo_device_check(int device_ordinal) { return select_device(device_ordinal); }
+
 extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   if (!cfg || !out)
     return set_err(nullptr, ALEPPO_ERR_INVALID_ARGUMENT, "null argument");
@@ -1152,11 +1154,14 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   int rc = ensure_metric_storage(c, epochs, M, B);
   if (rc)
     return rc;
-  for (hipStream_t *st : {&c->wg_stream, &c->comm_stream}) // created on first use: see aleppo_create
-    if (!*st)
-      HIPCHK(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
   ncclComm_t comm = static_cast<ncclComm_t>(c->nccl_comm);
   const bool dp = c->world > 1 || (c->nccl_comm && c->force_comm); // force_comm: 1-rank communicator (tests)
+  // side streams, created on first use (see aleppo_create): the weight-gradient stream, and - only with data parallelism -
+  // the communication stream
+  if (!c->wg_stream)
+    HIPCHK(c, hipStreamCreateWithFlags(&c->wg_stream, hipStreamNonBlocking));
+  if (dp && !c->comm_stream)
+    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   const int H = c->H, A = c->A, prec = c->prec;
   const ParamLayout &L = c->L;
   hipStream_t s = c->stream;
@@ -1202,7 +1207,6 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   launch_mask_count(s, c->mask_n, c->mask_counts, B, M);
   if (dp) // N_m of the masked mean is the GLOBAL count
     NCCLCHK(c, ncclAllReduce(c->mask_counts, c->mask_counts, M, ncclFloat, ncclSum, comm, s));
-  bool pack_pending = false;
   for (int ep = 0; ep < epochs; ++ep)
     for (int mb = 0; mb < M; ++mb) { // contiguous env-major slices; randperm unused (Q1)
       const int mi = ep * M + mb;
@@ -1219,10 +1223,6 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
                         c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr, hparts,
                         wg_pipe ? sBfc : nullptr, c->rt16);
       prof_end(c, ALEPPO_K_HEAD);
-      if (pack_pending) { // the previous minibatch's repacked dgrad weights
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
-        pack_pending = false;
-      }
       HIPCHK(c, fork(c->ev_head)); // dh is ready
       prof_begin(c, ALEPPO_K_FC_DGRAD);
       fc_dgrad(s, prec, c->dh, c->WfcT, c->a3, c->dz3, B, H);
@@ -1333,20 +1333,12 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_begin(c, ALEPPO_K_ADAM);
       // (pads between tensors are zero: only [0, off[P_W1]) and the two conv1 tensors contribute)
       const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail);
-      launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, prec, (long)L.total(),
-                  c->sumsq_part, nblk_norm, hp.max_norm, c->adam_sched + 2 * mi, c->cfg.adam_beta1, c->cfg.adam_beta2,
-                  c->cfg.adam_eps, c->grad_norms + mi);
+      // (the Adam kernel also writes the bf16 compute copy and the dgrad-side transposed layouts W2d / W3d / WfcT)
+      launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, c->WfcT, c->W3d, c->W2d,
+                  L, prec, c->sumsq_part, nblk_norm, hp.max_norm, c->adam_sched + 2 * mi, c->cfg.adam_beta1,
+                  c->cfg.adam_beta2, c->cfg.adam_eps, c->grad_norms + mi);
       prof_end(c, ALEPPO_K_ADAM);
-      // The dgrad weight layouts (W2d, W3d, WfcT) are first needed by the NEXT minibatch's fc dgrad: repack them
-      // on the side stream, off the critical path, while the next forward pass runs.
-      HIPCHK(c, hipEventRecord(c->ev_adam, s));
-      HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_adam, 0));
-      launch_pack_dgrad(c->comm_stream, c->P, L, c->W2d, c->W3d, c->WfcT, prec);
-      HIPCHK(c, hipEventRecord(c->ev_pack, c->comm_stream));
-      pack_pending = true;
     }
-  if (pack_pending)
-    HIPCHK(c, hipStreamWaitEvent(s, c->ev_pack, 0));
   launch_metrics_reduce(s, c->metric_ps, fs, c->mask_n, B, M, epochs, c->metric_red);
   if (dp)
     NCCLCHK(c, ncclAllReduce(c->metric_red, c->metric_red, (size_t)nm * 8, ncclFloat, ncclSum, comm, s));

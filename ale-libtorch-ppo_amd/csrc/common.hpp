@@ -243,8 +243,11 @@ void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *
 // squares G[0, n_main) in nblk_main blocks + the two tail tensors (slab sums fused when tail[i].slab != nullptr);
 // returns the number of partials written (<= 1024)
 int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2]);
+// clip + Adam over the whole flat vector; also refreshes the compute copy Pc (bf16) and the dgrad-side transposed weight
+// layouts WfcT / W3d / W2d (both precisions) from the updated parameters in the same pass
 void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
-                 int prec, long n, const float *partials, int nblk, float max_norm,
+                 void *WfcT, void *W3d, void *W2d, const ParamLayout &L, int prec, const float *partials, int nblk,
+                 float max_norm,
                  const float *sched, // device: { lr / (1 - beta1^t), sqrt(1 - beta2^t) } of this step
                  float beta1, float beta2, float eps, float *grad_norm_out);
 void launch_pack_dgrad(hipStream_t s, const float *P, const ParamLayout &L, void *W2d, void *W3d, void *WfcT,

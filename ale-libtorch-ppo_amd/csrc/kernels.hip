@@ -1029,12 +1029,46 @@ int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk
   return nblk; // partials written
 }
 
+struct long4_ranges {
+  long begin[4], len[4];
+};
+// One Adam step of element i (train.cc:42-44 clip scale always applied; torch::optim::Adam's update form)
+struct AdamScalars {
+  float coef, step_size, bc2_sqrt, beta1, beta2, omb1, omb2, eps;
+};
+__device__ __forceinline__ float adam_element(long i, float *P, const float *__restrict__ G, float *Gs, float *M1,
+                                              float *M2, const AdamScalars &a) {
+  const float g = G[i] * a.coef;
+  const float m = M1[i] * a.beta1 + a.omb1 * g;
+  const float v = M2[i] * a.beta2 + a.omb2 * (g * g);
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  const float p = P[i] - a.step_size * (m / denom);
+  M1[i] = m;
+  M2[i] = v;
+  P[i] = p;
+  if (Gs)
+    Gs[i] = g;
+  return p;
+}
+// The dgrad-side weight layouts are TRANSPOSES of three weight tensors (W3d[c][(tap,oc)], W2d[class][c][(ab,oc)],
+// WfcT[j][o]): the blocks that own those tensors walk them in 64-row tiles, write the updated weight to the compute copy
+// in place and - through an LDS transpose, so that both sides are whole lines - to its transposed home.  (Until round 3
+// two extra kernels re-read P on a side stream after every optimizer step: 28 us and 9.6 MB per step.)
+struct AdamTiles {
+  // tile t of tensor k: rows r0..r0+63 (row stride rs), cols c0..c0+cols-1 contiguous at src = off + r*rs + c;
+  // transposed element (c, r) at dst + c*ds + r
+  long off[3];      // Wfc, W3, W2 offsets in the flat vector
+  int first[4];     // first tile index of each tensor (+ total)
+  int H;
+};
 template <class T>
 __global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__restrict__ G, float *Gs, float *M1, float *M2,
-                                                    T *Pc, long n, const float *__restrict__ partials, int nblk,
+                                                    T *Pc, T *WfcT, T *W3d, T *W2d, AdamTiles tl, long n_flat,
+                                                    long4_ranges fr, const float *__restrict__ partials, int nblk,
                                                     float max_norm, const float *__restrict__ sched, float beta1,
                                                     float beta2, float eps, float *grad_norm_out) {
   __shared__ float s4[4];
+  __shared__ float tile[64][65];
   float s = 0.f;
   for (int i = threadIdx.x; i < nblk; i += 256)
     s += partials[i];
@@ -1046,35 +1080,106 @@ __global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__rest
     *grad_norm_out = norm;                // pre-clip norm is what the reference reports (Q9)
   // lr / (1 - beta1^t) and sqrt(1 - beta2^t) of THIS optimizer step: device scalars (a captured hipGraph of the update
   // follows the annealed rate and the step count; the reference's captured graph bakes both, train.h:163-195)
-  const float step_size = sched[0], bc2_sqrt = sched[1];
-  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float g = G[i] * coef;          // train.cc:42-44 (always applied)
-    const float m = M1[i] * beta1 + omb1 * g;
-    const float v = M2[i] * beta2 + omb2 * (g * g);
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    const float p = P[i] - step_size * (m / denom);
-    M1[i] = m;
-    M2[i] = v;
-    P[i] = p;
-    if (Gs)
-      Gs[i] = g;
+  const AdamScalars a{coef, sched[0], sched[1], beta1, beta2, 1.0f - beta1, 1.0f - beta2, eps};
+  const int ntile = tl.first[3];
+  if ((int)blockIdx.x < ntile) { // a 64-row tile of Wfc / W3 / W2
+    const int t = blockIdx.x;
+    long src;      // flat index of tile element (0, 0)
+    int rs, rows, cols;
+    T *dst;        // transposed element (c, r) at dst[c * ds + r]
+    int ds;
+    if (t < tl.first[1]) {          // Wfc[o][j] -> WfcT[j][o]: tile (o-block, j-block of 64; 3136 = 49 * 64)
+      const int ob = t / 49, jb = t - ob * 49;
+      rs = FC_IN;
+      rows = min(64, tl.H - ob * 64);
+      cols = 64;
+      src = tl.off[0] + (long)ob * 64 * FC_IN + jb * 64;
+      dst = WfcT + (long)jb * 64 * tl.H + ob * 64;
+      ds = tl.H;
+    } else if (t < tl.first[2]) {   // W3[oc][tap][c] -> W3d[c][tap][oc]: one tile per tap
+      const int tap = t - tl.first[1];
+      rs = 576;
+      rows = 64;
+      cols = 64;
+      src = tl.off[1] + tap * 64;
+      dst = W3d + tap * 64;
+      ds = 576;
+    } else {                        // W2[oc][(kh,kw)][c] -> W2d[class][c][(ab)][oc]: one 64 x 32 tile per (kh, kw)
+      const int k = t - tl.first[2], kh = k >> 2, kw = k & 3;
+      const int cls = (kh & 1) * 2 + (kw & 1), ab = (kh >> 1) * 2 + (kw >> 1);
+      rs = 512;
+      rows = 64;
+      cols = 32;
+      src = tl.off[2] + k * 32;
+      dst = W2d + cls * (32 * 256) + ab * 64;
+      ds = 256;
+    }
+    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+    if (c < cols)
+      for (int r = r4; r < rows; r += 4) {
+        const long i = src + (long)r * rs + c;
+        const float p = adam_element(i, P, G, Gs, M1, M2, a);
+        if (Pc)
+          Pc[i] = (T)p;
+        tile[r][c] = p;
+      }
+    __syncthreads();
+    const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
+    if (r < rows)
+      for (int cc = c4; cc < cols; cc += 4)
+        dst[(long)cc * ds + r] = (T)tile[r][cc];
+    return;
+  }
+  // everything else, flat: index k of the compacted space of the (at most four) ranges between the tiled tensors
+  const long stride = (long)(gridDim.x - ntile) * 256;
+  for (long k = (long)((int)blockIdx.x - ntile) * 256 + threadIdx.x; k < n_flat; k += stride) {
+    long i = k;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (i < fr.len[q]) {
+        i += fr.begin[q];
+        break;
+      }
+      i -= fr.len[q];
+    }
+    const float p = adam_element(i, P, G, Gs, M1, M2, a);
     if (Pc)
       Pc[i] = (T)p;
   }
 }
 void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
-                 int prec, long n, const float *partials, int nblk, float max_norm, const float *sched,
-                 float beta1, float beta2, float eps, float *grad_norm_out) {
-  const int nb = (int)std::min<long>((n + 255) / 256, 2048);
+                 void *WfcT, void *W3d, void *W2d, const ParamLayout &L, int prec, const float *partials, int nblk,
+                 float max_norm, const float *sched, float beta1, float beta2, float eps, float *grad_norm_out) {
+  AdamTiles tl;
+  tl.off[0] = (long)L.off[P_WFC];
+  tl.off[1] = (long)L.off[P_W3];
+  tl.off[2] = (long)L.off[P_W2];
+  tl.H = L.H;
+  tl.first[0] = 0;
+  tl.first[1] = (L.H + 63) / 64 * 49;
+  tl.first[2] = tl.first[1] + 9;
+  tl.first[3] = tl.first[2] + 16;
+  // flat ranges: [0, Wfc) heads, [bfc, W3), [b3, W2), [b2, end) (pads between tensors included: zero and stay zero)
+  long4_ranges fr;
+  const long edges[8] = {0, (long)L.off[P_WFC], (long)L.off[P_BFC], (long)L.off[P_W3], (long)L.off[P_B3],
+                         (long)L.off[P_W2], (long)L.off[P_B2], (long)L.total()};
+  long n_flat = 0;
+  for (int q = 0; q < 4; ++q) {
+    fr.begin[q] = edges[2 * q];
+    fr.len[q] = edges[2 * q + 1] - edges[2 * q];
+    n_flat += fr.len[q];
+  }
+  const int nb = tl.first[3] + (int)std::min<long>((n_flat + 255) / 256, 1024);
   if (prec == ALEPPO_BF16)
     hipLaunchKernelGGL(adam_kernel<bf16>, dim3(nb), dim3(256), 0, s, P, G_in, G_out_scaled, M1, M2,
-                       static_cast<bf16 *>(Pc), n, partials, nblk, max_norm, sched, beta1, beta2, eps,
+                       static_cast<bf16 *>(Pc), static_cast<bf16 *>(WfcT), static_cast<bf16 *>(W3d),
+                       static_cast<bf16 *>(W2d), tl, n_flat, fr, partials, nblk, max_norm, sched, beta1, beta2, eps,
                        grad_norm_out);
   else
     hipLaunchKernelGGL(adam_kernel<float>, dim3(nb), dim3(256), 0, s, P, G_in, G_out_scaled, M1, M2,
-                       static_cast<float *>(nullptr), n, partials, nblk, max_norm, sched, beta1, beta2,
-                       eps, grad_norm_out);
+                       static_cast<float *>(nullptr), static_cast<float *>(WfcT), static_cast<float *>(W3d),
+                       static_cast<float *>(W2d), tl, n_flat, fr, partials, nblk, max_norm, sched, beta1, beta2, eps,
+                       grad_norm_out);
 }
 
 __global__ void cast_params_kernel(const float *P, bf16 *Pc, long n) {

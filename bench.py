@@ -103,6 +103,10 @@ def run(args):
             log("spawning: " + " ".join(cmd))
             raise SystemExit(subprocess.call(cmd))
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch exactly one rank per GPU")
+    if "WORLD_SIZE" in os.environ:  # one line per rank: what the launcher handed over
+        log(f"rank {rank} local_rank {local_rank} world_size {world} master "
+            f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}")
+    load_package().device_check(local_rank)  # fails loudly (ALEPPO_ERR_NO_DEVICE) before anything else touches a device
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -337,14 +341,24 @@ def run(args):
     if rank == 0 and world == 1 and not args.no_host_legs:
         host_legs = {}
         hsteps = max(2, min(args.steps, 5))
-        for leg, kind, per_env in (("frames_84_mapped_host", pkg.FRAMES_84, 84 * 84),
-                                   ("raw_pair_mapped_host", pkg.FRAMES_RAW_PAIR, 2 * 210 * 160)):
+        # (+ the metric's own wording, "84x84x4 uint8 batches": finished 84x84 frames resident in HBM, no preprocessing)
+        for leg, kind, per_env, loc in (("frames_84_hbm", pkg.FRAMES_84, 84 * 84, pkg.DEVICE),
+                                        ("frames_84_mapped_host", pkg.FRAMES_84, 84 * 84, pkg.HOST_MAPPED),
+                                        ("raw_pair_mapped_host", pkg.FRAMES_RAW_PAIR, 2 * 210 * 160, pkg.HOST_MAPPED)):
             try:
-                mh = MappedHost(T * E * per_env)
-                if kind == pkg.FRAMES_RAW_PAIR:
-                    mh.fill_from(frames.cpu().numpy())
+                f84 = np.random.default_rng(7).integers(0, 256, (T, E, 84, 84), dtype=np.uint8)
+                if loc == pkg.DEVICE:
+                    class _Dev:  # same interface as MappedHost, frames in HBM
+                        def __init__(self, arr):
+                            self.t = torch.from_numpy(arr).cuda()
+                            self.addr = self.t.data_ptr()
+
+                        def free(self):
+                            del self.t
+                    mh = _Dev(f84)
                 else:
-                    mh.fill_from(np.random.default_rng(7).integers(0, 256, (T, E, 84, 84), dtype=np.uint8))
+                    mh = MappedHost(T * E * per_env)
+                    mh.fill_from(frames.cpu().numpy() if kind == pkg.FRAMES_RAW_PAIR else f84)
                 rs = 0
                 plan_j = 0
                 for i in range(1 + hsteps):
@@ -353,7 +367,7 @@ def run(args):
                     if i == 1:
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
-                    eng.replay_rollout(mh.addr, kind, E * per_env, rew, te, tr, st, location=pkg.HOST_MAPPED)
+                    eng.replay_rollout(mh.addr, kind, E * per_env, rew, te, tr, st, location=loc)
                     eng.finish_rollout()
                     eng.train(2.5e-4, epochs, M)
                     if i >= 1:
@@ -363,8 +377,8 @@ def run(args):
                 mh.free()
                 host_legs[leg] = {"value": round(rs / hdt, 1), "unit": "env-steps/s", "steps": hsteps,
                                   "ms_per_step": round(hdt / hsteps * 1e3, 3),
-                                  "pcie_bytes_per_slot": E * per_env}
-                log(f"host leg {leg}: {rs / hdt:.0f} env-steps/s")
+                                  "pcie_bytes_per_slot": E * per_env if loc != pkg.DEVICE else 0}
+                log(f"frame leg {leg}: {rs / hdt:.0f} env-steps/s")
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write(f"host-frames leg {leg} failed: {e}\n")
 
@@ -386,7 +400,8 @@ def run(args):
                        "rollout_planes": "fp16" if args.rollout_fp16 else "fp32",
                        "update_graph": bool(args.update_graph),
                        "dp_schedule_forced": bool(args.force_comm and world == 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "host_frames": host_legs,
+            "roofline": roofline, "cpu_baseline": cpu,
+            "frames_84_hbm": (host_legs or {}).pop("frames_84_hbm", None), "host_frames": host_legs,
             "vs_reference_published_v1_26289": round(value / 26289.0, 2), "v1_shape": v1,
             "last_loss": float(metrics["loss"][-1, -1]), "last_grad_norm": float(metrics["grad_norm"][-1, -1]),
         }

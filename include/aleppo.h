@@ -125,6 +125,9 @@ typedef enum {
 
 /* ------------------------------------------------------------------ lifetime */
 int aleppo_abi_version(void);
+/* ALEPPO_OK if HIP device `device_ordinal` exists and is a gfx950; ALEPPO_ERR_NO_DEVICE / _INVALID_ARGUMENT otherwise
+ * (the check aleppo_create makes, on its own: what main() learns from torch::cuda::is_available(), train.cc:336-345). */
+int aleppo_device_check(int device_ordinal);
 /* Replaces the construction done in main(): Network + Adam + Rollout(+Buffer) (train.cc:358-387). */
 int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out);
 void aleppo_destroy(aleppo_ctx *ctx);

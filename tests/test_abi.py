@@ -80,6 +80,27 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
 
 
+def test_bench_spawns_one_rank_per_gpu_with_the_launcher_environment():
+    """`python bench.py --gpus 2` outside a launcher starts torch.distributed.run itself (as a child, before it touches a
+    device): each of the two ranks reports the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it was handed and - this
+    container has no GPU - stops at aleppo_device_check with ALEPPO_ERR_NO_DEVICE (no CPU fallback, no silent skip).
+    SURVEY 8e; the reference is single-device (src/bin/train.cc:336-345)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run the bench")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--master-port", "29531"], capture_output=True, text=True, env=env, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "spawning:" in out and "--nproc-per-node=2" in out
+    for rank in (0, 1):
+        assert f"rank {rank} local_rank {rank} world_size 2 master 127.0.0.1:29531" in out, out[-3000:]
+    assert out.count("no CPU fallback") >= 2, out[-3000:]
+
+
 def test_option_and_location_constants_match_the_header(pkg):
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aleppo.h")).read(), flags=re.S)
     for name, val in (("ALEPPO_OPT_GENERIC_CONV", pkg.OPT_GENERIC_CONV), ("ALEPPO_OPT_FC_PIPE", pkg.OPT_FC_PIPE),
