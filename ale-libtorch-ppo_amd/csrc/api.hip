@@ -33,8 +33,6 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   Tuning t;
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
-  t.fc_pipe_wgrad = flag("ALEPPO_FC_PIPE_WGRAD", false);
-  t.fuse_c2d_c1w = flag("ALEPPO_FUSE_C2D_C1W", false);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -431,7 +429,6 @@ extern "C" int aleppo_create(const aleppo_config *cfg, aleppo_ctx **out) {
   CK(dalloc(&c->mask_counts, 4096 * 4, c->stream));
   CK(dalloc(&c->P, PT * 4, c->stream));
   CK(dalloc(&c->G, PT * 4, c->stream));
-  CK(dalloc(&c->Gs, PT * 4, c->stream));
   CK(dalloc(&c->M1, PT * 4, c->stream));
   CK(dalloc(&c->M2, PT * 4, c->stream));
   if (c->prec == ALEPPO_BF16)
@@ -577,7 +574,19 @@ extern "C" int aleppo_export_params(aleppo_ctx *c, float *flat, size_t count) {
 }
 extern "C" int aleppo_export_grads(aleppo_ctx *c, float *flat, size_t count) {
   CHECK_CTX(c);
-  return export_flat(c, c->Gs, flat, count);
+  // clip_grad_norm_ scales in place (train.cc:42-44); the Adam kernel applies the same factor on the fly and leaves G as the
+  // backward pass produced it (a separate scaled copy cost 4 bytes per parameter and optimizer step).  The factor is one
+  // fp32 product of the stored pre-clip norm: applied here it gives the bits the kernel multiplied into its update.
+  const int rc = export_flat(c, c->G, flat, count);
+  if (rc || c->last_epochs * c->last_M == 0)
+    return rc;
+  const size_t nm = (size_t)c->last_epochs * c->last_M;
+  const float norm = c->h_metric_red[nm * 8 + nm - 1];
+  float coef = c->cfg.max_gradient_norm / (norm + 1e-6f);
+  coef = std::fmin(coef, 1.0f);
+  for (size_t i = 0; i < count; ++i)
+    flat[i] *= coef;
+  return ALEPPO_OK;
 }
 
 extern "C" int aleppo_export_optimizer(aleppo_ctx *c, float *exp_avg, float *exp_avg_sq, int64_t *step,
@@ -1134,6 +1143,14 @@ static int ensure_metric_storage(aleppo_ctx *c, int epochs, int M, long B) {
   return ALEPPO_OK;
 }
 
+static bool fuse_tail_env() { // A/B switch: conv1's slab reduce fused into the sum-of-squares pass (default)
+  static const bool v = [] {
+    const char *e = getenv("ALEPPO_FUSE_TAIL_REDUCE");
+    return !e || atoi(e) != 0;
+  }();
+  return v;
+}
+
 extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_minibatch_metrics *out) {
   CHECK_CTX(c);
   if (epochs <= 0 || M <= 0)
@@ -1213,7 +1230,6 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const long n0 = (long)mb * B;
       const SampleMap map = train_map(c, n0);
       const int hparts = net_forward(c, c->obs, map, B, FC_FWD_MAX_PARTS);
-      const bool wg_pipe = fc_wgrad_pipelined(prec, B, H); // then the head kernel also emits the fc bias gradient
       prof_begin(c, ALEPPO_K_HEAD);
       launch_head_train(s, c->h, Pf(c, P_WH), Pf(c, P_BH), c->act_n + n0, rp(c, c->oldlp_n, (size_t)n0 * A),
                         rp(c, c->adv_n, (size_t)n0), rp(c, c->ret_n, (size_t)n0), c->mask_n + n0, c->mask_counts + mb, hp,
@@ -1221,7 +1237,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
                         c->metric_ps + 0 * fs + (size_t)mi * B, c->metric_ps + 1 * fs + (size_t)mi * B,
                         c->metric_ps + 2 * fs + (size_t)mi * B, c->metric_ps + 3 * fs + (size_t)mi * B,
                         c->metric_ps + 4 * fs + (size_t)mi * B, sWh, sBh, nblk_head, B, H, A, nullptr, nullptr, hparts,
-                        wg_pipe ? sBfc : nullptr, c->rt16);
+                        c->rt16);
       prof_end(c, ALEPPO_K_HEAD);
       HIPCHK(c, fork(c->ev_head)); // dh is ready
       prof_begin(c, ALEPPO_K_FC_DGRAD);
@@ -1229,7 +1245,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_end(c, ALEPPO_K_FC_DGRAD);
       prof_begin(c, ALEPPO_K_FC_WGRAD, sw);
       // split-K slabs (or, with one slice, straight into the gradient tensor)
-      const bool fc_direct = !wg_pipe && fc_wgrad_slices(prec, B) == 1;
+      const bool fc_direct = fc_wgrad_slices(prec, B) == 1;
       const int Sfc = fc_wgrad(sw, prec, c->dh, c->a3, fc_direct ? c->G + L.off[P_WFC] : sWfc,
                                fc_direct ? c->G + L.off[P_BFC] : sBfc, B, H);
       prof_end(c, ALEPPO_K_FC_WGRAD, sw);
@@ -1238,7 +1254,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const ReduceSeg segs0[4] = {{sWh, nblk_head, (long)(A + 1) * H, (long)L.off[P_WH]},
                                   {sBh, nblk_head, (long)A + 1, (long)L.off[P_BH]},
                                   {sWfc, Sfc, (long)H * FC_IN, (long)L.off[P_WFC]},
-                                  {sBfc, wg_pipe ? nblk_head : Sfc, (long)H, (long)L.off[P_BFC]}};
+                                  {sBfc, Sfc, (long)H, (long)L.off[P_BFC]}};
       const int nseg0 = fc_direct ? 2 : 4;
       // bucket 0 is reduced early only for the all-reduce overlap: on one GPU an early reduce next to the conv dgrads
       // measured slower (8.60 vs 8.38 ms per update) than one reduce of all ten slab groups at the end
@@ -1263,19 +1279,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
       prof_end(c, ALEPPO_K_CONV3_WGRAD, sw);
       HIPCHK(c, fork(c->ev_dz2)); // dz2 is ready
-      // bf16: conv2's data gradient and conv1's weight gradient run as ONE launch (conv_fuse.hpp): dz1 goes from the
-      // dgrad's accumulators through LDS into the wgrad's MFMAs and never reaches HBM
-      const bool fuse21 = prec == ALEPPO_BF16 && use_patch_kernels() && c->tune.fuse_c2d_c1w;
-      int S1 = 0;
-      if (fuse21) {
-        prof_begin(c, ALEPPO_K_CONV2D_CONV1W);
-        S1 = patch_conv2_dgrad_conv1_wgrad(s, c->dz2, c->W2d, c->a1, c->obs, map, sW1, sB1, B);
-        prof_end(c, ALEPPO_K_CONV2D_CONV1W);
-      } else {
-        prof_begin(c, ALEPPO_K_CONV2_DGRAD);
-        conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
-        prof_end(c, ALEPPO_K_CONV2_DGRAD);
-      }
+      prof_begin(c, ALEPPO_K_CONV2_DGRAD);
+      conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
+      prof_end(c, ALEPPO_K_CONV2_DGRAD);
       prof_begin(c, ALEPPO_K_CONV2_WGRAD, sw);
       const int S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
       prof_end(c, ALEPPO_K_CONV2_WGRAD, sw);
@@ -1289,17 +1295,27 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       if (!early0)
         for (int i = 0; i < nseg0; ++i)
           segs[nseg++] = segs0[i];
+      // sumsq_side: the sum of squares of everything but conv1 follows the reduce on the weight-gradient stream, still
+      // beside conv1 wgrad; after the join only conv1's slab sums + squares (129 blocks) and Adam are left
+      static const bool sumsq_side_env = [] {
+        const char *e = getenv("ALEPPO_SUMSQ_SIDE");
+        return !e || atoi(e) != 0;
+      }();
+      bool sumsq_side = false;
       if (two) {
         prof_begin(c, ALEPPO_K_REDUCE, sw);
         launch_reduce_slabs(sw, segs, nseg, c->G);
         prof_end(c, ALEPPO_K_REDUCE, sw);
         nseg = 0;
+        sumsq_side = sumsq_side_env && !dp && fuse_tail_env();
       }
-      if (!fuse21) {
-        prof_begin(c, ALEPPO_K_CONV1_WGRAD);
-        S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
-        prof_end(c, ALEPPO_K_CONV1_WGRAD);
+      if (sumsq_side) { // (tail descriptors are not read by the main blocks)
+        const ReduceSeg none[2] = {{nullptr, 0, 32 * 256, (long)L.off[P_W1]}, {nullptr, 0, 32, (long)L.off[P_B1]}};
+        launch_sumsq(sw, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, none, 1);
       }
+      prof_begin(c, ALEPPO_K_CONV1_WGRAD);
+      const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
+      prof_end(c, ALEPPO_K_CONV1_WGRAD);
       if (two) { // join: sumsq / Adam read the whole gradient
         HIPCHK(c, hipEventRecord(c->ev_wg, sw));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_wg, 0));
@@ -1307,10 +1323,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       // conv1's slabs: with data parallelism they are reduced now (the all-reduce needs the whole gradient); on one GPU
       // the sum-of-squares pass below sums them on the fly - one launch less on the serial tail of the minibatch.
       ReduceSeg tail[2] = {{sW1, S1, 32 * 256, (long)L.off[P_W1]}, {sB1, S1, 32, (long)L.off[P_B1]}};
-      static const bool fuse_tail = [] { // A/B switch
-        const char *e = getenv("ALEPPO_FUSE_TAIL_REDUCE");
-        return !e || atoi(e) != 0;
-      }();
+      const bool fuse_tail = fuse_tail_env();
       if (dp || !fuse_tail) {
         segs[nseg++] = tail[0];
         segs[nseg++] = tail[1];
@@ -1332,9 +1345,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       }
       prof_begin(c, ALEPPO_K_ADAM);
       // (pads between tensors are zero: only [0, off[P_W1]) and the two conv1 tensors contribute)
-      const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail);
+      const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail, sumsq_side ? 2 : 0);
       // (the Adam kernel also writes the bf16 compute copy and the dgrad-side transposed layouts W2d / W3d / WfcT)
-      launch_adam(s, c->P, c->G, c->Gs, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, c->WfcT, c->W3d, c->W2d,
+      launch_adam(s, c->P, c->G, nullptr, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, c->WfcT, c->W3d, c->W2d,
                   L, prec, c->sumsq_part, nblk_norm, hp.max_norm, c->adam_sched + 2 * mi, c->cfg.adam_beta1,
                   c->cfg.adam_beta2, c->cfg.adam_eps, c->grad_norms + mi);
       prof_end(c, ALEPPO_K_ADAM);
@@ -1661,10 +1674,6 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->tune.patch_conv = value == 0;
   else if (option == ALEPPO_OPT_FC_PIPE)
     c->tune.fc_pipe = value != 0;
-  else if (option == ALEPPO_OPT_FC_PIPE_WGRAD)
-    c->tune.fc_pipe_wgrad = value != 0;
-  else if (option == ALEPPO_OPT_FUSE_C2D_C1W)
-    c->tune.fuse_c2d_c1w = value != 0;
   else if (option == ALEPPO_OPT_FUSED_ACT)
     c->tune.fused_act = value; // 0: never, 1: where it is faster (default), 2: always
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
@@ -1691,9 +1700,7 @@ extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
   case ALEPPO_OPT_FORCE_COMM: *value = c->force_comm; break;
   case ALEPPO_OPT_SERIAL_UPDATE: *value = c->serial_update; break;
   case ALEPPO_OPT_FC_PIPE: *value = c->tune.fc_pipe; break;
-  case ALEPPO_OPT_FC_PIPE_WGRAD: *value = c->tune.fc_pipe_wgrad; break;
   case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
-  case ALEPPO_OPT_FUSE_C2D_C1W: *value = c->tune.fuse_c2d_c1w; break;
   case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
   case ALEPPO_OPT_GATE_TIMEOUT_MS: *value = (int64_t)(c->gate_timeout_ticks / 100000ull); break;
   default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");
@@ -1998,7 +2005,7 @@ extern "C" int aleppo_ppo_loss(int dev, const float *logits, const float *old_lp
   launch_head_train(op.st, dh_in.as<float>(), dW.as<float>(), db.as<float>(), ac.as<int>(), ol.as<float>(),
                     ad.as<float>(), re.as<float>(), ma.as<uint8_t>(), cnt.as<float>(), Hyper{clip, c_v, c_e, 0.f},
                     dh_out.p, ALEPPO_FP32, p, p + B, p + 2 * B, p + 3 * B, p + 4 * B, sw.as<float>(), sb.as<float>(),
-                    nblk, B, H, (int)A, nullptr, nullptr, 1, nullptr);
+                    nblk, B, H, (int)A, nullptr, nullptr, 1);
   launch_metrics_reduce(op.st, p, (size_t)B, ma.as<uint8_t>(), B, 1, 1, red.as<float>());
   OPCHK(op.sync());
   float r8[8];

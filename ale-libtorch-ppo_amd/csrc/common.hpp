@@ -60,11 +60,6 @@ struct Hyper {
 struct Tuning {
   bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
   bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
-  bool fc_pipe_wgrad = false; // opt-in pipelined fc wgrad
-  // conv2 dgrad + conv1 wgrad in one launch (dz1 never leaves the CU): 210 MB less HBM traffic per 4096-sample minibatch and
-  // 111 us instead of 55 + 68 us alone on the GPU, but its 111 KB of LDS keeps conv2's weight-gradient kernel (co-scheduled
-  // on the second stream) off the same CU: 7.90 vs 7.80 ms per update in the timed two-stream schedule -> opt-in
-  bool fuse_c2d_c1w = false;
   int fused_act = 1;          // frame ingest fused in front of the acting convolutions: 0 never, 1 where faster, 2 always
 };
 const Tuning &tuning();
@@ -136,7 +131,7 @@ struct Ctx {
   uint8_t *mask_n = nullptr;
   float *mask_counts = nullptr; // [M_max] global unmasked count per minibatch
   // ---- network state ----
-  float *P = nullptr, *G = nullptr, *Gs = nullptr, *M1 = nullptr, *M2 = nullptr; // fp32, internal layout (Gs: clipped G)
+  float *P = nullptr, *G = nullptr, *Gs = nullptr, *M1 = nullptr, *M2 = nullptr; // fp32, internal layout (Gs: unused)
   void *Pc = nullptr;   // compute copy of P in T (same layout); == P for fp32
   void *W2d = nullptr, *W3d = nullptr, *WfcT = nullptr; // dgrad-transposed copies in T
   int64_t adam_step = 0;
@@ -231,8 +226,7 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
                        long B, int H, int A, float *logits_out, float *values_out, int hparts = 1,
-                       float *slab_bfc = nullptr, // slab_bfc: [nblk][H] column sums of dh (fc bias gradient)
-                       bool rt16 = false);        // oldlp / adv / ret are f16 planes
+                       bool rt16 = false); // oldlp / adv / ret are f16 planes
 struct ReduceSeg {
   const float *slab;
   int S;
@@ -242,7 +236,8 @@ struct ReduceSeg {
 void launch_reduce_slabs(hipStream_t s, const ReduceSeg *segs, int nseg, float *G);
 // squares G[0, n_main) in nblk_main blocks + the two tail tensors (slab sums fused when tail[i].slab != nullptr);
 // returns the number of partials written (<= 1024)
-int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2]);
+int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2],
+                 int which = 0);
 // clip + Adam over the whole flat vector; also refreshes the compute copy Pc (bf16) and the dgrad-side transposed weight
 // layouts WfcT / W3d / W2d (both precisions) from the updated parameters in the same pass
 void launch_adam(hipStream_t s, float *P, const float *G_in, float *G_out_scaled, float *M1, float *M2, void *Pc,
@@ -284,7 +279,6 @@ void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, cons
 // wgrads write split-K slabs; return the number of slices S used (slab holds S*[M*N] then bias S*[M])
 int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *slab_w, float *slab_b, long ns, int H);
 int fc_wgrad_slices(int prec, long ns); // number of split-K slices fc_wgrad will use for ns samples
-bool fc_wgrad_pipelined(int prec, long ns, int H); // pipelined kernel: no bias slab (head_train_kernel sums dh)
 int conv3_wgrad(hipStream_t s, int prec, const void *dz3, const void *a2, float *slab_w, float *slab_b, long ns);
 int conv2_wgrad(hipStream_t s, int prec, const void *dz2, const void *a1, float *slab_w, float *slab_b, long ns);
 int conv1_wgrad(hipStream_t s, int prec, const void *dz1, const uint32_t *obs, SampleMap map, float *slab_w,
@@ -307,8 +301,6 @@ void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns);
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns);
-int patch_conv2_dgrad_conv1_wgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, const uint32_t *obs,
-                                  SampleMap map, float *sw, float *sb, long ns);
 int patch_conv3_wgrad(hipStream_t s, const void *dz3, const void *a2, float *sw, float *sb, long ns);
 
 } // namespace aleppo

@@ -1,8 +1,8 @@
 // conv1 weight gradient (bf16), tap-shift formulation.   dW1[oc][kh][kw][c] = sum_{n,oy,ox} dz1[n][oy][ox][oc] * obs[n][4oy+kh][4ox+kw][c]
 //
-// The implicit-GEMM form (conv_wgrad_patch_kernel<LConv1Wgrad>, M = 32 channels, N = 256 taps, K = pixels) reads one
+// The implicit-GEMM form (rounds 1-2, an instantiation of conv_wgrad_patch_kernel: M = 32 channels, N = 256 taps, K = pixels; deleted in round 3) read one
 // im2col fragment of the staged frame stack from LDS per TWO matrix instructions (there are only two 16-channel atoms
-// to use it for) and is bound by exactly that: its consumer waves move 205 KB of fragments per half sample through an LDS
+// to use it for) and was bound by exactly that: its consumer waves moved 205 KB of fragments per half sample through an LDS
 // port that delivers 128 B per clock to `ds_read_b64_tr_b16` - 1,600 of the ~1,650 clocks the multiply phase takes alone
 // on the CU (in-kernel `s_memtime` stamps; the staging waves never wait for HBM).  This kernel reads less:
 //

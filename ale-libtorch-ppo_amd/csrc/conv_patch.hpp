@@ -780,11 +780,8 @@ template <class L> constexpr size_t conv_patch_smem() {
 // ================================================================================================
 // wgrad: dW[oc][j] = sum over (sample, pixel) of dY[pixel][oc] * im2col(X)[pixel][j]
 // ================================================================================================
-struct LConv1Wgrad { // half-sample units like LConv1Fwd
-  using InT = uint8_t;
-  static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OC = 32, NJ = 256,
-                       SB = 1, MI = 2, NI = 2, WM = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, PF2 = 1, SPEC = 1; // wave: 2 oc x 2 of 16 j atoms
-};
+// (conv1's weight gradient has its own kernel, conv1_wgrad.hpp; its implicit-GEMM instantiation of the kernel below - packed
+// uint8 input, producer / consumer wave specialisation - was the round-1/2 form and is gone)
 struct LConv2Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OC = 64, NJ = 512, SB = 1,

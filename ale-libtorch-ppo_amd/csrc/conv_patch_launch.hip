@@ -4,7 +4,6 @@
 #include "conv_patch.hpp"
 #include "conv1_wgrad.hpp"
 #include "conv3_tile.hpp"
-#include "conv_fuse.hpp"
 #include <cstdlib>
 
 namespace aleppo {
@@ -139,16 +138,21 @@ template <class L> static int launch_wgrad(hipStream_t s, const WgradParams &P) 
     once = true;
   }
   const long ngroups = (P.ns * L::GPS + L::SB - 1) / L::SB;
-  const int grid = (int)std::min<long>(ngroups, std::min(num_cus(), MAXS_C1));
+  // Half the CUs: every workgroup writes one fp32 slab of the whole dW (147 KB for conv3), and these kernels run on the
+  // weight-gradient stream in the shadow of the dgrad chain, so fewer, longer workgroups cost nothing there and halve what
+  // the slab reduce reads beside conv1 wgrad (measured per 4096-sample minibatch, same box: 256 workgroups 455 us,
+  // 192: 451, 160: 450, 128: 444, 96: 455; ALEPPO_WG_GRID overrides)
+  static const int cap = [] {
+    const char *e = std::getenv("ALEPPO_WG_GRID");
+    return e ? std::atoi(e) : num_cus() / 2;
+  }();
+  const int grid = (int)std::min<long>(ngroups, std::min(std::min(num_cus(), MAXS_C1), cap));
   hipLaunchKernelGGL((conv_wgrad_patch_kernel<L>), dim3(grid), dim3(512), sm, s, P);
   return grid;
 }
 int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, SampleMap map, float *sw, float *sb,
                       long ns) {
   WgradParams P{obs, static_cast<const bf16 *>(dz1), sw, sb, ns, map, 1.0f / 255.0f};
-  static const bool legacy = std::getenv("ALEPPO_C1W_LEGACY") != nullptr; // implicit-GEMM form (A/B)
-  if (legacy)
-    return launch_wgrad<LConv1Wgrad>(s, P);
   static bool once = false;
   if (!once) {
     allow_smem(conv1_wgrad_shift_kernel, c1w::SMEM);
@@ -156,20 +160,6 @@ int patch_conv1_wgrad(hipStream_t s, const void *dz1, const uint32_t *obs, Sampl
   }
   const int grid = (int)std::min<long>(2 * ns, std::min(num_cus(), MAXS_C1));
   hipLaunchKernelGGL(conv1_wgrad_shift_kernel, dim3(grid), dim3(c1w::NTHREADS), c1w::SMEM, s, P);
-  return grid;
-}
-// conv2 dgrad + conv1 wgrad in one launch (conv_fuse.hpp); returns the number of slabs written
-int patch_conv2_dgrad_conv1_wgrad(hipStream_t s, const void *dz2, const void *W2d, const void *a1, const uint32_t *obs,
-                                  SampleMap map, float *sw, float *sb, long ns) {
-  static bool once = false;
-  if (!once) {
-    allow_smem(conv2_dgrad_conv1_wgrad_kernel, F21_SMEM);
-    once = true;
-  }
-  FuseC2dC1wParams P{static_cast<const bf16 *>(dz2), static_cast<const bf16 *>(W2d), static_cast<const bf16 *>(a1),
-                     reinterpret_cast<const uint8_t *>(obs), map, sw, sb, ns, 1.0f / 255.0f};
-  const int grid = (int)std::min<long>(ns, std::min(num_cus(), MAXS_C1));
-  hipLaunchKernelGGL(conv2_dgrad_conv1_wgrad_kernel, dim3(grid), dim3(512), F21_SMEM, s, P);
   return grid;
 }
 int patch_conv2_wgrad(hipStream_t s, const void *dz2, const void *a1, float *sw, float *sb, long ns) {

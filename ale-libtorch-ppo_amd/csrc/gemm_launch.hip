@@ -10,7 +10,7 @@
 namespace aleppo {
 
 // tile-shape A/B switches: every call site keeps its value in a function-local static (read once per process); the
-// switches the tests flip at run time (fc_pipe, fc_pipe_wgrad, patch_conv) are per-context options (tuning())
+// switches the tests flip at run time (fc_pipe, patch_conv) are per-context options (tuning())
 static int tune(const char *name, int dflt) {
   const char *e = std::getenv(name);
   return e ? std::atoi(e) : dflt;
@@ -144,47 +144,6 @@ static void fc_dgrad_pipe(hipStream_t s, const void *dh, const void *WfcT, const
   P.out_bf16 = static_cast<bf16 *>(dz3);
   P.gate = static_cast<const bf16 *>(a3);
   launch_pipe<1, 4>(s, P);
-}
-// wgrad (MODE 2): dWfc[H][3136] split-K slabs; bias gradient comes from head_train_kernel.  ns % 64 == 0.
-static int fc_wgrad_pipe_slices(long ns, int H) {
-  const int tiles = ((H + 127) / 128) * ((FC_IN + 127) / 128), cus = pipe_cus(), nst = (int)(ns / 64);
-  int best = 0;
-  double best_t = 1e30;
-  for (int sp = 2; sp <= MAXS_FC; ++sp) { // >= 4 k-stages per job (ring depth)
-    if (nst / sp < 4)
-      break;
-    const double t = (double)((tiles * sp + cus - 1) / cus) * ((nst + sp - 1) / sp) + 3.0 * sp; // rounds x stages + slab write/reduce traffic, in k-stage units
-    if (t < best_t - 1e-9) {
-      best_t = t;
-      best = sp;
-    }
-  }
-  return best; // 0: shape not supported
-}
-// Measured on MI355X (4096 x 512 x 3136): 51-57 us against 48 us for the register-staged gemm_tn kernel - walking DOWN
-// the rows of both k-major operands the LDS-DMA stream runs at ~1.4 us per 64-sample stage, twice the NT kernels'
-// rate (not LDS conflicts, not the dh row pitch, not XCD placement: all measured).  Kept as an opt-in
-// (ALEPPO_FC_PIPE_WGRAD=1) that the parity tests cover; the default is the gemm_tn kernel.
-bool fc_wgrad_pipelined(int prec, long ns, int H) {
-  return prec == ALEPPO_BF16 && use_pipe() && tuning().fc_pipe_wgrad && ns > 256 && ns % 64 == 0 && H % 8 == 0 &&
-         H >= 8 && fc_wgrad_pipe_slices(ns, H) >= 2;
-}
-static int fc_wgrad_pipe(hipStream_t s, const void *dh, const void *a3, float *sw, long ns, int H) {
-  PipeParams P{};
-  P.A = static_cast<const bf16 *>(dh);
-  P.lda = H;
-  P.B = static_cast<const bf16 *>(a3);
-  P.ldb = FC_IN;
-  P.M = H;
-  P.N = FC_IN;
-  P.tiles_m = (H + 127) / 128;
-  P.tiles_n = (FC_IN + 127) / 128;
-  P.nstages = (int)(ns / 64);
-  P.splits = fc_wgrad_pipe_slices(ns, H);
-  P.njobs = P.tiles_m * P.tiles_n * P.splits;
-  P.out_f32 = sw;
-  launch_pipe<2, 4>(s, P);
-  return P.splits;
 }
 template <class T>
 static void fc_fwd_t(hipStream_t s, const void *a3, const void *Wfc, const float *bfc, float *h, long ns, int H) {
@@ -507,14 +466,12 @@ void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, cons
     return patch_conv2_dgrad(s, dz2, W2d, a1, dz1, ns);
   DISPATCH(prec, conv2_dgrad_t<float>(s, dz2, W2d, a1, dz1, ns), conv2_dgrad_t<bf16>(s, dz2, W2d, a1, dz1, ns));
 }
-int fc_wgrad_slices(int prec, long ns) { // (non-pipelined path; the pipelined one always has >= 2 slices)
+int fc_wgrad_slices(int prec, long ns) {
   static const int smax = tune("ALEPPO_FC_WGRAD_SPLIT", 4);
   const int KP = prec == ALEPPO_BF16 ? Atom<bf16>::KT : Atom<float>::KT;
   return (int)std::max<long>(1, std::min<long>(std::min(smax, MAXS_FC), ns / (4 * KP)));
 }
 int fc_wgrad(hipStream_t s, int prec, const void *dh, const void *a3, float *sw, float *sb, long ns, int H) {
-  if (fc_wgrad_pipelined(prec, ns, H))
-    return fc_wgrad_pipe(s, dh, a3, sw, ns, H);
   if (prec == ALEPPO_BF16)
     return fc_wgrad_t<bf16>(s, dh, a3, sw, sb, ns, H);
   return fc_wgrad_t<float>(s, dh, a3, sw, sb, ns, H);

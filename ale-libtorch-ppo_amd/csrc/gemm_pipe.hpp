@@ -29,12 +29,8 @@
 //        tile is DMA'd into LDS like a stage (an ordinary global load would make hipcc drain the DMA queue),
 //        gated in place and written back with whole 256-byte rows.  Needs >= NST k-stages per job.
 //
-// MODE 2 (fc wgrad): C[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands k-major (A = dh [samples][H],
-//        B = a3 [samples][3136]), split-K fp32 slabs [splits][M][N].  A stage is 64 samples: tiles land in LDS as
-//        [k][128 columns] (256-byte rows, XOR-swizzled on the DMA source: slot s of row k holds 16-byte column chunk
-//        s ^ (((k & 3) << 2) | ((k >> 2) & 3))), and the MFMA operands are gathered with ds_read_b64_tr_b16: two
-//        transposed 4-row blocks per fragment, the two 16-lane groups of a half-wave 8 rows apart (conflict-free).
-//        Both operands use the same lane -> k map, so the permutation of the 32 k's of a step cancels.
+// (A transposed-gather variant for the weight gradient - both operands k-major, ds_read_b64_tr_b16 fragments - was built
+// and measured in rounds 1-2: 51-57 us against 45 us for gemm_tn_kernel; deleted in round 3.)
 //
 // Wait-count rule used throughout: `s_waitcnt vmcnt(N)` is safe iff N <= the number of vector-memory
 // instructions this wave ISSUED after the batch it needs (they retire in issue order).  Under-counting only
@@ -148,22 +144,16 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
   auto set_src = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if constexpr (MODE == 2) { // rows are k (64 per stage), 16 column chunks per row
-        const int r = er0 + 32 * i, ch = eslot ^ (((r & 3) << 2) | ((r >> 2) & 3));
-        pa[i] = P.A + ((long)pjob.ks0 * 64 + r) * P.lda + min(pjob.m0 + ch * 8, P.M - 8);
-        pb[i] = P.B + ((long)pjob.ks0 * 64 + r) * P.ldb + min(pjob.n0 + ch * 8, P.N - 8);
-      } else {
-        const int r = r0 + 64 * i, sw = (slot ^ (r & 7)) * 8;
-        pa[i] = P.A + (long)min(pjob.m0 + r, P.M - 1) * P.lda + (long)pjob.ks0 * 64 + sw;
-        pb[i] = P.B + (long)min(pjob.n0 + r, P.N - 1) * P.ldb + (long)pjob.ks0 * 64 + sw;
-      }
+      const int r = r0 + 64 * i, sw = (slot ^ (r & 7)) * 8;
+      pa[i] = P.A + (long)min(pjob.m0 + r, P.M - 1) * P.lda + (long)pjob.ks0 * 64 + sw;
+      pb[i] = P.B + (long)min(pjob.n0 + r, P.N - 1) * P.ldb + (long)pjob.ks0 * 64 + sw;
     }
   };
   set_src();
   // one batch = 4 LDS-DMA instructions per wave (pieces 0,1: A rows r0, r0 + 64; 2,3: B rows), then advance()
   auto piece = [&](int q) {
     u32x4 *dst = ring + pbuf * PIPE_STAGE_CHUNKS + wave * 64;
-    const long ka = MODE == 2 ? (long)pk * 64 * P.lda : (long)pk * 64, kb = MODE == 2 ? (long)pk * 64 * P.ldb : (long)pk * 64;
+    const long ka = (long)pk * 64, kb = (long)pk * 64;
     if (q < 2)
       __builtin_amdgcn_global_load_lds((gptr)(pa[q] + ka), (lptr)(dst + 512 * q), 16, 0, 0);
     else
@@ -180,34 +170,13 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
   };
 
   // fragment reads of the stage in ring buffer `buf`
-  // MODE 2: transposed gather.  Lane (i = lane & 15, g = lane >> 4), q = i >> 2, p = i & 3 supplies the address of
-  // 4 columns of row (32 kc + 8 (g & 1) + 16 (g >> 1) + q) for the first block and 4 rows below for the second.
-  const int tq = fr >> 2, tp = fr & 3;
-  const int trow = 8 * (fg & 1) + 16 * (fg >> 1) + tq;
-  const int tsw1 = ((tq << 2) | (2 * (fg & 1))) ^ (tp >> 1), tsw2 = tsw1 ^ 1; // chunk = c0 ^ tsw (c0 even)
-  typedef __attribute__((address_space(3))) bf16x4 *lds4;
-  auto read_tr = [&](const uint8_t *tile, int kc, int c0) {
-    const uint8_t *p1 = tile + (kc * 32 + trow) * 256 + ((c0 ^ tsw1) * 16) + 8 * (tp & 1);
-    const uint8_t *p2 = tile + (kc * 32 + trow + 4) * 256 + ((c0 ^ tsw2) * 16) + 8 * (tp & 1);
-    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p1));
-    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p2));
-    return u32x4{lo[0], lo[1], hi[0], hi[1]};
-  };
   auto read_a = [&](PipeFrags &f, int buf, int kc, int i) {
-    if constexpr (MODE == 2) {
-      f.a[kc][i] = read_tr(smem + (size_t)buf * PIPE_STAGE_CHUNKS * 16, kc, wm * 8 + i * 2);
-    } else {
-      const int r = wm * 64 + i * 16 + fr;
-      f.a[kc][i] = ring[buf * PIPE_STAGE_CHUNKS + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
-    }
+    const int r = wm * 64 + i * 16 + fr;
+    f.a[kc][i] = ring[buf * PIPE_STAGE_CHUNKS + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
   };
   auto read_b = [&](PipeFrags &f, int buf, int kc, int j) {
-    if constexpr (MODE == 2) {
-      f.b[kc][j] = read_tr(smem + ((size_t)buf * PIPE_STAGE_CHUNKS + 1024) * 16, kc, wn * 4 + j * 2);
-    } else {
-      const int r = wn * 32 + j * 16 + fr;
-      f.b[kc][j] = ring[buf * PIPE_STAGE_CHUNKS + 1024 + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
-    }
+    const int r = wn * 32 + j * 16 + fr;
+    f.b[kc][j] = ring[buf * PIPE_STAGE_CHUNKS + 1024 + r * 8 + ((kc * 4 + fg) ^ (r & 7))];
   };
 
   f32x4 acc[4][2];
@@ -304,7 +273,7 @@ template <int MODE, int NST> __global__ __launch_bounds__(512) void gemm_pipe_ke
     }
     if (++ck == cjob.nks) { // ---------------- epilogue of this job
       const int mrow = cjob.m0 + wm * 64 + fr, ncol = cjob.n0 + wn * 32 + fg * 4;
-      if constexpr (MODE == 0 || MODE == 2) {
+      if constexpr (MODE == 0) {
         float *out = P.out_f32 + (long)cjob.slice * P.M * P.N;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
     const int *__restrict__ act, const RT *__restrict__ oldlp, const RT *__restrict__ adv,
     const RT *__restrict__ ret, const uint8_t *__restrict__ mask, const float *__restrict__ mask_count, Hyper hp,
     T *dh, float *ps_total, float *ps_clipped, float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w,
-    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc) {
+    float *slab_b, long B, int H, int A, float *logits_out, float *values_out, int hparts) {
   constexpr int A1 = AMAX + 1, HPL = 8; // H <= 512: 8 hidden units per lane
   constexpr int NWV = AMAX > 10 ? 4 : 8; // waves per workgroup
   extern __shared__ float smem[];
@@ -613,10 +613,7 @@ __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
     sW[i] = Wh[i];
   __syncthreads();
   const float inv_nm = 1.0f / mask_count[0];
-  float gW[A1][HPL], gb[A1], gfc[HPL]; // gfc: column sums of dh = the fc bias gradient (when slab_bfc is given)
-#pragma unroll
-  for (int i = 0; i < HPL; ++i)
-    gfc[i] = 0.f;
+  float gW[A1][HPL], gb[A1];
 #pragma unroll
   for (int a = 0; a < A1; ++a) {
     gb[a] = 0.f;
@@ -747,10 +744,8 @@ __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
         }
       T dr[HPL];
 #pragma unroll
-      for (int i = 0; i < HPL; ++i) {
+      for (int i = 0; i < HPL; ++i)
         dr[i] = (T)d[i];
-        gfc[i] += (float)dr[i]; // the rounded value the fc wgrad GEMM multiplies with
-      }
       T *dst = dh + (size_t)row * H + lane * 4;
       if constexpr (sizeof(T) == 2) {
         *reinterpret_cast<u32x2 *>(dst) = reinterpret_cast<const u32x2 *>(dr)[0];
@@ -798,22 +793,6 @@ __global__ __launch_bounds__(AMAX > 10 ? 256 : 512) void head_train_kernel(
       sb += sB[w * A1 + tid];
     slab_b[(size_t)blockIdx.x * (A + 1) + tid] = sb;
   }
-  if (slab_bfc) { // same fixed-order cross-wave reduction for the fc bias gradient
-#pragma unroll
-    for (int i = 0; i < HPL; ++i) {
-      const int j = (i < 4 ? 0 : H / 2) + lane * 4 + (i & 3);
-      if (lane * 8 < H)
-        sPart[wave * H + j] = gfc[i];
-    }
-    __syncthreads();
-    for (int j = tid; j < H; j += 64 * NWV) {
-      float sum = 0.f;
-#pragma unroll
-      for (int w = 0; w < NWV; ++w)
-        sum += sPart[w * H + j];
-      slab_bfc[(size_t)blockIdx.x * H + j] = sum;
-    }
-  }
 }
 
 template <class T, class RT>
@@ -821,7 +800,7 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
                          const RT *oldlp, const RT *adv, const RT *ret, const uint8_t *mask,
                          const float *mask_count, Hyper hp, void *dh, float *ps_total, float *ps_clipped,
                          float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                         long B, int H, int A, float *lo, float *vo, int hparts, float *slab_bfc) {
+                         long B, int H, int A, float *lo, float *vo, int hparts) {
 #define LAUNCH_HEAD(AM)                                                                                                \
   do {                                                                                                                 \
     const size_t sm = ((size_t)((AM + 1) + ((AM + 1) > 8 ? (AM + 1) : 8)) * H + 8 * (AM + 1)) * sizeof(float);        \
@@ -830,7 +809,7 @@ static void head_train_t(hipStream_t s, const float *h, const float *Wh, const f
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                                  \
     hipLaunchKernelGGL((head_train_kernel<T, AM, RT>), dim3(nblk), dim3(AM > 10 ? 256 : 512), sm, s, h, Wh, bh, act, oldlp, adv, ret,  \
                        mask, mask_count, hp, static_cast<T *>(dh), ps_total, ps_clipped, ps_value, ps_entropy,         \
-                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts, slab_bfc);                                         \
+                       ps_ratio, slab_w, slab_b, B, H, A, lo, vo, hparts);                                                   \
   } while (0)
   if (A <= 4)
     LAUNCH_HEAD(4);
@@ -846,12 +825,11 @@ void launch_head_train(hipStream_t s, const float *h, const float *Wh, const flo
                        const void *oldlp, const void *adv, const void *ret, const uint8_t *mask,
                        const float *mask_count, Hyper hp, void *dh, int prec, float *ps_total, float *ps_clipped,
                        float *ps_value, float *ps_entropy, float *ps_ratio, float *slab_w, float *slab_b, int nblk,
-                       long B, int H, int A, float *logits_out, float *values_out, int hparts, float *slab_bfc,
-                       bool rt16) {
+                       long B, int H, int A, float *logits_out, float *values_out, int hparts, bool rt16) {
 #define HEAD_ARGS(RT)                                                                                                  \
   s, h, Wh, bh, act, static_cast<const RT *>(oldlp), static_cast<const RT *>(adv), static_cast<const RT *>(ret), mask, \
       mask_count, hp, dh, ps_total, ps_clipped, ps_value, ps_entropy, ps_ratio, slab_w, slab_b, nblk, B, H, A,         \
-      logits_out, values_out, hparts, slab_bfc
+      logits_out, values_out, hparts
   if (prec == ALEPPO_BF16) {
     if (rt16)
       head_train_t<bf16, f16>(HEAD_ARGS(f16));
@@ -976,17 +954,18 @@ struct SumsqTail {
   int chunks[2];    // 64-output chunks per tensor
 };
 __global__ __launch_bounds__(256) void sumsq_kernel(float *__restrict__ G, long n, float *partials, int nmain,
-                                                    SumsqTail tail) {
+                                                    SumsqTail tail, int boff) {
   __shared__ float s4[4];
   __shared__ float part[4][64];
   float s = 0.f;
-  if ((int)blockIdx.x < nmain) {
+  const int blk = (int)blockIdx.x + boff; // (a launch may cover only the main blocks or only the tail blocks)
+  if (blk < nmain) {
     const long per = (n + nmain - 1) / nmain;
-    const long b = (long)blockIdx.x * per, e = min(n, b + per);
+    const long b = (long)blk * per, e = min(n, b + per);
     for (long i = b + threadIdx.x; i < e; i += 256)
       s += G[i] * G[i];
   } else {
-    int c = (int)blockIdx.x - nmain, t = 0;
+    int c = blk - nmain, t = 0;
     if (c >= tail.chunks[0]) {
       c -= tail.chunks[0];
       t = 1;
@@ -1016,17 +995,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(float *__restrict__ G, long 
   }
   s = block_sum_256(s, s4);
   if (threadIdx.x == 0)
-    partials[blockIdx.x] = s;
+    partials[blk] = s;
 }
-int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2]) {
+// which: 0 = every block; 1 = only the blocks of G[0, n_main) (everything but the tail tensors: may run as soon as those
+// gradients are reduced, beside the last weight-gradient kernel); 2 = only the tail tensors' blocks.  The partials and
+// their order are the same however the blocks are launched.
+int launch_sumsq(hipStream_t s, float *G, long n_main, float *partials, int nblk_main, const ReduceSeg tail[2],
+                 int which) {
   SumsqTail t;
   for (int i = 0; i < 2; ++i) {
     t.seg[i] = tail[i];
     t.chunks[i] = (int)((tail[i].n + 63) / 64);
   }
-  const int nblk = nblk_main + t.chunks[0] + t.chunks[1];
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, s, G, n_main, partials, nblk_main, t);
-  return nblk; // partials written
+  const int ntail = t.chunks[0] + t.chunks[1], nblk = nblk_main + ntail;
+  const int first = which == 2 ? nblk_main : 0, count = which == 1 ? nblk_main : nblk - first;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(count), dim3(256), 0, s, G, n_main, partials, nblk_main, t, first);
+  return nblk; // partials written once every block has run
 }
 
 struct long4_ranges {
@@ -1115,14 +1099,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float *P, const float *__rest
       ds = 256;
     }
     const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
-    if (c < cols)
-      for (int r = r4; r < rows; r += 4) {
-        const long i = src + (long)r * rs + c;
-        const float p = adam_element(i, P, G, Gs, M1, M2, a);
-        if (Pc)
-          Pc[i] = (T)p;
-        tile[r][c] = p;
+    if (c < cols) {
+      // all 64 loads of a thread's 16 elements are issued before the first store (P / M1 / M2 are read and written through
+      // the same pointers, so the compiler may not hoist them itself; a dependent load-compute-store chain per element made
+      // this kernel latency-bound: 23 vs 13 us)
+      float g[16], m1[16], m2[16], p0[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int r = r4 + 4 * k;
+        const long i = src + (long)(r < rows ? r : 0) * rs + c;
+        g[k] = G[i];
+        m1[k] = M1[i];
+        m2[k] = M2[i];
+        p0[k] = P[i];
       }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int r = r4 + 4 * k;
+        if (r < rows) {
+          const long i = src + (long)r * rs + c;
+          const float gg = g[k] * a.coef;
+          const float m = m1[k] * a.beta1 + a.omb1 * gg;
+          const float v = m2[k] * a.beta2 + a.omb2 * (gg * gg);
+          const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+          const float p = p0[k] - a.step_size * (m / denom);
+          M1[i] = m;
+          M2[i] = v;
+          P[i] = p;
+          if (Gs)
+            Gs[i] = gg;
+          if (Pc)
+            Pc[i] = (T)p;
+          tile[r][c] = p;
+        }
+      }
+    }
     __syncthreads();
     const int r = threadIdx.x & 63, c4 = threadIdx.x >> 6;
     if (r < rows)

@@ -28,7 +28,7 @@ from __graft_entry__ import load_package  # noqa: E402
 KFLOP = dict(conv1_fwd=2 * 400 * 32 * 256, conv2_fwd=2 * 81 * 64 * 512, conv3_fwd=2 * 49 * 64 * 576,
              fc_fwd=2 * 3136 * 512, fc_dgrad=2 * 3136 * 512, fc_wgrad=2 * 3136 * 512, conv3_dgrad=2 * 49 * 64 * 576,
              conv3_wgrad=2 * 49 * 64 * 576, conv2_dgrad=2 * 81 * 64 * 512, conv2_wgrad=2 * 81 * 64 * 512,
-             conv1_wgrad=2 * 400 * 32 * 256, conv2d_conv1w=2 * 81 * 64 * 512 + 2 * 400 * 32 * 256)
+             conv1_wgrad=2 * 400 * 32 * 256)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -41,8 +41,7 @@ def kernel_bytes(dtype):
     dh = 512 * e
     return dict(conv1_fwd=obs + a1, conv2_fwd=a1 + a2, conv3_fwd=a2 + a3, fc_fwd=a3 + h, fc_dgrad=dh + 2 * a3,
                 fc_wgrad=dh + a3, conv3_dgrad=a3 + 2 * a2, conv3_wgrad=a3 + a2, conv2_dgrad=a2 + 2 * a1,
-                conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs,
-                conv2d_conv1w=a2 + a1 + obs)  # fused: dz2 + ReLU gates a1 + packed observation in, nothing but slabs out
+                conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs)
 
 
 def log(msg):
@@ -106,9 +105,9 @@ def run(args):
     if "WORLD_SIZE" in os.environ:  # one line per rank: what the launcher handed over
         log(f"rank {rank} local_rank {local_rank} world_size {world} master "
             f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}")
-    load_package().device_check(local_rank)  # fails loudly (ALEPPO_ERR_NO_DEVICE) before anything else touches a device
-    import torch
+    import torch  # (first: libaleppo.so must bind to the HIP runtime torch ships, not load a second one)
     import torch.distributed as dist
+    load_package().device_check(local_rank)  # fails loudly (ALEPPO_ERR_NO_DEVICE) before anything else touches a device
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -269,8 +268,7 @@ def run(args):
         # dominant kernel = the longest one on the update's CRITICAL PATH (main stream: forward chain, dgrad chain, conv1
         # wgrad).  The weight-gradient kernels of the second stream run in the main stream's shadow and stretch with it
         # (fc wgrad: 38 us alone, 72 us beside fc dgrad + conv3 dgrad): their timed-region durations are not a cost.
-        main_stream = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv2_dgrad", "conv1_wgrad",
-                       "conv2d_conv1w")
+        main_stream = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv2_dgrad", "conv1_wgrad")
         dom = max((k for k in table if k in main_stream), key=lambda k: trn[k][0] * trn[k][1])
         d = table[dom]
         # HBM traffic of the dominant kernel: recorded by `tests/tools/pmc_traffic.py` (rocprofv3 --pmc passes cannot run

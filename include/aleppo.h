@@ -302,8 +302,7 @@ typedef enum {
   ALEPPO_K_REDUCE = 15,     /* split-K slab reduction */
   ALEPPO_K_INFER_HEAD = 16, /* action head + sampling */
   ALEPPO_K_ACT_FUSED = 17,  /* frame ingest + conv1-3 of the acting batch in one launch (aleppo_step, bf16) */
-  ALEPPO_K_CONV2D_CONV1W = 18, /* conv2 dgrad + conv1 wgrad in one launch (bf16; replaces classes 12 and 14) */
-  ALEPPO_K_COUNT = 19
+  ALEPPO_K_COUNT = 18
 } aleppo_kernel_class;
 int aleppo_profile_enable(aleppo_ctx *ctx, int on);
 int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);
@@ -317,11 +316,10 @@ typedef enum {
   ALEPPO_OPT_SERIAL_UPDATE = 3,    /* measurement: run the weight-gradient kernels on the main stream too (isolated
                                       per-kernel timings; default 0 = co-scheduled on a second stream) */
   ALEPPO_OPT_FC_PIPE = 4,          /* 0: small-tile fc GEMMs instead of the pipelined LDS-DMA ones (A/B, parity tests) */
-  ALEPPO_OPT_FC_PIPE_WGRAD = 5,    /* 1: pipelined fc weight gradient (opt-in, measured slower) */
+  /* 5 and 8 were the opt-in pipelined fc weight gradient and the fused conv2-dgrad + conv1-wgrad launch: both measured
+     slower than the defaults in rounds 1-3 and were deleted */
   ALEPPO_OPT_FUSED_ACT = 6,        /* frame ingest fused in front of the acting convolutions (bf16): 0 never, 1 where it
                                       is faster (default: given 84x84 frames, raw pairs in mapped host memory), 2 always */
-  ALEPPO_OPT_FUSE_C2D_C1W = 8,     /* 1: conv2 dgrad + conv1 wgrad as ONE launch, dz1 never reaches HBM (opt-in: less traffic,
-                                      faster alone, slower beside the co-scheduled conv2 wgrad) */
   ALEPPO_OPT_GATE_TIMEOUT_MS = 9,  /* exit condition of the slot-ahead gate in milliseconds (default 120 000; also the
                                       environment variable ALEPPO_GATE_TIMEOUT_MS at aleppo_create) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it

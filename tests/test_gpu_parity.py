@@ -371,7 +371,6 @@ def test_bf16_pipelined_fc_gemms_match_small_tile_kernels(pkg, N, M, H):
     for pipe in (0, 1):
         eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
         eng.set_option(pkg.OPT_FC_PIPE, pipe)        # per-context switches (aleppo_set_option)
-        eng.set_option(pkg.OPT_FC_PIPE_WGRAD, pipe)  # the opt-in pipelined wgrad (transposed LDS gathers) too
         eng.load_params(params)
         eng.set_batch(obs, actions, old_lp, adv, ret, masks)
         m = eng.train(2.5e-4, 2, M)
