@@ -1212,6 +1212,12 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
   }();
   const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
+  // (Tried in round 3, tests/tools/forkbench.hip: in isolation an event record + wait costs the pair of streams ~12 us
+  // per dependency, a one-wave signal kernel + a one-wave gate kernel on a device word ~3 us.  In the update it changes
+  // nothing or loses: with signal kernels the weight-gradient kernel is released BEFORE the dgrad kernel beside it has its
+  // workgroups on the CUs and the dgrad chain slows down (485 vs 458 us per minibatch); with the dgrad kernel itself
+  // announcing its start the main stream runs without gaps - and the minibatch takes 445 vs 444 us: the two streams
+  // together keep the GPU saturated, so a gap on one is filled by the other.  DESIGN.md 4a.)
   auto fork = [&](hipEvent_t ev) -> hipError_t { // sw continues after everything enqueued on s so far
     if (!two)
       return hipSuccess;
@@ -1295,23 +1301,11 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       if (!early0)
         for (int i = 0; i < nseg0; ++i)
           segs[nseg++] = segs0[i];
-      // sumsq_side: the sum of squares of everything but conv1 follows the reduce on the weight-gradient stream, still
-      // beside conv1 wgrad; after the join only conv1's slab sums + squares (129 blocks) and Adam are left
-      static const bool sumsq_side_env = [] {
-        const char *e = getenv("ALEPPO_SUMSQ_SIDE");
-        return !e || atoi(e) != 0;
-      }();
-      bool sumsq_side = false;
       if (two) {
         prof_begin(c, ALEPPO_K_REDUCE, sw);
         launch_reduce_slabs(sw, segs, nseg, c->G);
         prof_end(c, ALEPPO_K_REDUCE, sw);
         nseg = 0;
-        sumsq_side = sumsq_side_env && !dp && fuse_tail_env();
-      }
-      if (sumsq_side) { // (tail descriptors are not read by the main blocks)
-        const ReduceSeg none[2] = {{nullptr, 0, 32 * 256, (long)L.off[P_W1]}, {nullptr, 0, 32, (long)L.off[P_B1]}};
-        launch_sumsq(sw, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, none, 1);
       }
       prof_begin(c, ALEPPO_K_CONV1_WGRAD);
       const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
@@ -1345,7 +1339,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       }
       prof_begin(c, ALEPPO_K_ADAM);
       // (pads between tensors are zero: only [0, off[P_W1]) and the two conv1 tensors contribute)
-      const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail, sumsq_side ? 2 : 0);
+      const int nblk_norm = launch_sumsq(s, c->G, (long)L.off[P_W1], c->sumsq_part, nblk_sq, tail);
       // (the Adam kernel also writes the bf16 compute copy and the dgrad-side transposed layouts W2d / W3d / WfcT)
       launch_adam(s, c->P, c->G, nullptr, c->M1, c->M2, c->prec == ALEPPO_BF16 ? c->Pc : nullptr, c->WfcT, c->W3d, c->W2d,
                   L, prec, c->sumsq_part, nblk_norm, hp.max_norm, c->adam_sched + 2 * mi, c->cfg.adam_beta1,
