@@ -1329,13 +1329,14 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         prof_end(c, ALEPPO_K_REDUCE);
       }
       if (dp) {
-        HIPCHK(c, hipEventRecord(c->ev_bucket0, s));
-        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_bucket0, 0));
-        NCCLCHK(c, ncclAllReduce(c->G + L.bucket0_end, c->G + L.bucket0_end, L.total() - L.bucket0_end, ncclFloat,
-                                 ncclSum, comm, c->comm_stream));
-        HIPCHK(c, hipEventRecord(c->ev_comm1, c->comm_stream));
+        // Bucket 1 (the conv tensors, 0.35 MB) is on the critical path whatever stream carries it - nothing is left to
+        // overlap it with - so it runs on the MAIN stream: a round trip through the communication stream cost two more
+        // cross-stream dependencies (~12 us each, forkbench) in the serial tail of every minibatch (update with a 1-rank
+        // communicator: +31 -> +16 us per minibatch over the single-GPU schedule).  The wait for bucket 0's event comes
+        // first: two collectives of one communicator must never be in flight together.
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_comm0, 0));
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_comm1, 0));
+        NCCLCHK(c, ncclAllReduce(c->G + L.bucket0_end, c->G + L.bucket0_end, L.total() - L.bucket0_end, ncclFloat,
+                                 ncclSum, comm, s));
       }
       prof_begin(c, ALEPPO_K_ADAM);
       // (pads between tensors are zero: only [0, off[P_W1]) and the two conv1 tensors contribute)

@@ -14,6 +14,9 @@ E, T, A, H, M, EP = 128, 128, int(os.environ.get("KB_A", "4")), 512, int(os.envi
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 eng = pkg.Engine(E, T, A, H, precision=pkg.BF16, max_minibatch=E * T // M)
 eng.load_params(hf.fill_params(310, H, A))
+if os.environ.get("KB_FORCE_COMM"):  # the data-parallel schedule through a 1-rank RCCL communicator
+    eng.comm_init(pkg.Engine.comm_unique_id())
+    eng.set_option(pkg.OPT_FORCE_COMM, 1)
 rng = np.random.default_rng(0)
 N = E * T
 obs = rng.integers(0, 256, (N, 4, 84, 84), dtype=np.uint8)
