@@ -35,19 +35,19 @@ struct LConv1Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = uint8_t;
   static constexpr int IN_ELEMS = 44 * 84 * 4, PIX = 200, OW = 20, S = 4, IW = 84, C = 4, KW = 8, OUTC = 32, KS = 8,
-                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1, ONE_ATOM = 0;
+                       SB = 1, OG = 1, CLASSES = 1, GPS = 2, GSTRIDE = 40 * 84 * 4, CP = 4, RPAD = 0, SPAD = 0, STATIC_ATOMS = 1, ONE_ATOM = 0;
 };
 struct LConv2Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OUTC = 64, KS = 16,
-                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0, PF2 = 0, STATIC_ATOMS = 1, ONE_ATOM = 0;
+                       SB = 2, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 40, RPAD = 8, SPAD = 0, STATIC_ATOMS = 1, ONE_ATOM = 0;
 };
 struct LConv3Fwd {
   static constexpr int MODE = PM_FWD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OUTC = 64, KS = 18, SB = 6,
-                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32, PF2 = 0, STATIC_ATOMS = 0, ONE_ATOM = 0;
+                       OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, CP = 80, RPAD = 96, SPAD = 32, STATIC_ATOMS = 0, ONE_ATOM = 0;
 };
 // acting-size variants (ns <= 256): one sample per group so that every CU gets a workgroup
 struct LConv2FwdSmall : LConv2Fwd {
@@ -62,14 +62,14 @@ struct LConv3Dgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 49 * 64, PIX = 81, PW = 9, OH = 7, OW = 7, OCK = 64, TW = 3, OUTC = 64, KS = 18,
                        SB = 8, OG = 2, CLASSES = 1, GPS = 1, GSTRIDE = 0, C = 64, CP = 72, RPAD = 80, SPAD = 0,
-                       PRELOAD_GATES = 0, PF2 = 0, ONE_ATOM = 0;
+                       PRELOAD_GATES = 0, ONE_ATOM = 0;
 };
 struct LConv2Dgrad { // one parity class (py,px) of the 20x20 input per wave group; 2x2 live taps
   static constexpr int MODE = PM_DGRAD;
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 100, PW = 10, OH = 9, OW = 9, OCK = 64, TW = 2, OUTC = 32, KS = 8,
                        SB = 2, OG = 4, CLASSES = 4, GPS = 1, GSTRIDE = 0, C = 64, CP = 80, RPAD = 80, SPAD = 0,
-                       PRELOAD_GATES = 0, PF2 = 0, ONE_ATOM = 0;
+                       PRELOAD_GATES = 0, ONE_ATOM = 0;
 };
 
 // LDS image of one unit: pixel (row, col) of the source at row*RP + col*CP bf16 elements, units SP apart.  The pixel
@@ -183,7 +183,7 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
   struct Regs {
     u32x4 r[NV];
   };
-  Regs R0, R1;
+  Regs R0;
   auto gload = [&](Regs &RR, long grp) {
     u32x4 (&R)[NV] = RR.r;
     if constexpr (static_atoms<L>()) {
@@ -399,33 +399,17 @@ template <class L, int NW> __global__ __launch_bounds__(64 * NW) void conv_patch
 
   const long gs = gridDim.x;
   long grp = blockIdx.x;
-  if constexpr (STATIC && L::PF2 != 0) { // two register sets: the groups of the next two iterations are in flight
-    gload(R0, grp);
-    gload(R1, grp + gs);
-    swrite(R0, 0, grp);
+  // one group ahead, ONE register set (a second set - two groups in flight - cost conv1 fwd a wave of occupancy: 66 vs
+  // 55 us; section 4 of DESIGN.md)
+  gload(R0, grp);
+  swrite(R0, 0, grp);
+  gload(R0, grp + gs);
+  __syncthreads();
+  for (int it = 0; grp < ngroups; grp += gs, ++it) {
+    process(it & 1, grp);
+    swrite(R0, (it + 1) & 1, grp + gs);
     gload(R0, grp + 2 * gs);
     __syncthreads();
-    for (; grp < ngroups; grp += 2 * gs) {
-      process(0, grp);
-      swrite(R1, 1, grp + gs);
-      gload(R1, grp + 3 * gs);
-      __syncthreads();
-      process(1, grp + gs); // (a group past the end: no lane has a pixel, everything goes to the scratch)
-      swrite(R0, 0, grp + 2 * gs);
-      gload(R0, grp + 4 * gs);
-      __syncthreads();
-    }
-  } else {
-    gload(R0, grp);
-    swrite(R0, 0, grp);
-    gload(R0, grp + gs);
-    __syncthreads();
-    for (int it = 0; grp < ngroups; grp += gs, ++it) {
-      process(it & 1, grp);
-      swrite(R0, (it + 1) & 1, grp + gs);
-      gload(R0, grp + 2 * gs);
-      __syncthreads();
-    }
   }
 }
 
@@ -785,12 +769,12 @@ template <class L> constexpr size_t conv_patch_smem() {
 struct LConv2Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 400 * 32, PIX = 81, OW = 9, S = 2, IW = 20, C = 32, KW = 4, OC = 64, NJ = 512, SB = 1,
-                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40, PF2 = 0, SPEC = 0; // wave: all 4 oc atoms x 4 of the 32 j atoms
+                       MI = 4, NI = 4, WM = 1, GPS = 1, GSTRIDE = 0, CP = 40; // wave: all 4 oc atoms x 4 of the 32 j atoms
 };
 struct LConv3Wgrad {
   using InT = bf16;
   static constexpr int IN_ELEMS = 81 * 64, PIX = 49, OW = 7, S = 1, IW = 9, C = 64, KW = 3, OC = 64, NJ = 576, SB = 3,
-                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80, PF2 = 0, SPEC = 0; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
+                       MI = 2, NI = 9, WM = 2, GPS = 1, GSTRIDE = 0, CP = 80; // wave: 2 of 4 oc atoms x 9 of 36 j atoms
 };
 
 struct WgradParams {
@@ -804,8 +788,7 @@ struct WgradParams {
 };
 
 template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(WgradParams P) {
-  using InT = typename L::InT;
-  constexpr bool U8 = sizeof(InT) == 1;
+  static_assert(sizeof(typename L::InT) == 2, "bf16 layer input (conv1 has its own kernel)");
   constexpr int PATCH = L::IN_ELEMS;
   constexpr int KPIX = L::SB * L::PIX;            // reduction length per group
   constexpr int KS = (KPIX + 31) / 32;            // atom-k steps per group (tail rows of dY are zero)
@@ -814,15 +797,9 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   constexpr int X_ELEMS = (L::SB * LPATCH + 63) / 64 * 64;
   constexpr int DY_ELEMS = KS * 32 * DYS;
   constexpr int BUF_ELEMS = X_ELEMS + DY_ELEMS;
-  // SPEC: wave specialisation.  Waves 0-3 (one per SIMD) are PRODUCERS - they prefetch, widen / stage both operands and
-  // keep the bias sums - waves 4-7 are CONSUMERS that own the whole dW tile between them (twice the columns each) and
-  // issue nothing but fragment reads and MFMAs.  With every wave doing both jobs in lockstep the vector pipe (staging)
-  // and the matrix pipe took turns, barrier to barrier; a producer and a consumer wave on the same SIMD use them at the
-  // same time, and a group lasts max(staging, multiply) instead of their sum.
-  constexpr bool SP = L::SPEC != 0;
-  constexpr int NPROD = SP ? 256 : 512; // threads that stage
-  constexpr int NI = SP ? 2 * L::NI : L::NI;
-  constexpr int XV = L::SB * PATCH * (int)sizeof(InT) / 16, NXV = (XV + NPROD - 1) / NPROD;
+  constexpr int NPROD = 512; // every thread stages
+  constexpr int NI = L::NI;
+  constexpr int XV = L::SB * PATCH * 2 / 16, NXV = (XV + NPROD - 1) / NPROD;
   constexpr int DV = KPIX * L::OC / 8, NDV = (DV + NPROD - 1) / NPROD; // dY source vectors (8 bf16)
   constexpr int VPR = L::OC / 8;                  // dY vectors per pixel row
   constexpr int SEG = L::KW * L::C;
@@ -830,11 +807,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
   bf16 *sbuf = reinterpret_cast<bf16 *>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool producer = !SP || wave < 4, consumer = !SP || wave >= 4;
-  const int cw = SP ? (wave & 3) : wave; // consumer index
-  const int wm = cw % L::WM, wn = cw / L::WM;
+  const int wm = wave % L::WM, wn = wave / L::WM;
   const int li = lane & 15, lg = lane >> 4;
-  static_assert(!SP || L::WM == 1, "specialised form: consumers split the columns only");
 
   f32x4 acc[L::MI][NI];
 #pragma unroll
@@ -866,12 +840,10 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
 
   const long nunits = P.ns * L::GPS; // unit = sample or half sample; dY of unit u = rows [u*PIX, (u+1)*PIX)
   const long ngroups = (nunits + L::SB - 1) / L::SB;
-  // TWO register sets: the groups of the next two iterations are in flight while this one is multiplied (the kernel
-  // streams its operands: with one group ahead it sat at 3.5 TB/s = one group per memory round trip per CU)
   struct Regs {
     u32x4 x[NXV], d[NDV];
   };
-  Regs R0, R1;
+  Regs R0; // one group ahead (a second register set spills here)
   // Loads are UNCONDITIONAL (indices clamped instead of predicated, groups past the end re-read the last one): only
   // then can hipcc count the outstanding loads and wait for ONE register set (vmcnt(N)) instead of draining both.
   auto gload = [&](Regs &R, long grp) {
@@ -881,15 +853,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
       const int v = min(tid + NPROD * i, XV - 1);
-      if constexpr (U8) {
-        const long n = n0 / L::GPS + P.map.n0;
-        const long off = (n / P.map.TP) * P.map.s1 + (n % P.map.TP) * P.map.s0 + P.map.base;
-        RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const uint8_t *>(P.x) + off * 4 +
-                                                (n0 % L::GPS) * (long)L::GSTRIDE)[v];
-      } else {
-        const long u = min(n0 + v / (PATCH / 8), nunits - 1); // unit of this vector (clamped: tail group)
-        RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.x) + u * PATCH)[v % (PATCH / 8)];
-      }
+      const long u = min(n0 + v / (PATCH / 8), nunits - 1); // unit of this vector (clamped: tail group)
+      RX[i] = reinterpret_cast<const u32x4 *>(static_cast<const bf16 *>(P.x) + u * PATCH)[v % (PATCH / 8)];
     }
 #pragma unroll
     for (int i = 0; i < NDV; ++i) {
@@ -910,21 +875,8 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
       if (v < XV) {
         if (u0 + v / (XV / L::SB) >= nunits)
           RX[i] = zero16();
-        if constexpr (U8) {
-          auto pk = [](uint32_t lo, uint32_t hi) {
-            return pack_u8_pair_bf16(lo, hi);
-          };
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const uint32_t w0 = RX[i][2 * d], w1 = RX[i][2 * d + 1];
-            reinterpret_cast<u32x4 *>(dx)[2 * v + d] =
-                u32x4{pk(w0 & 255u, (w0 >> 8) & 255u), pk((w0 >> 16) & 255u, w0 >> 24),
-                      pk(w1 & 255u, (w1 >> 8) & 255u), pk((w1 >> 16) & 255u, w1 >> 24)};
-          }
-        } else {
-          constexpr int VPP = L::C / 8;
-          *reinterpret_cast<u32x4 *>(dx + (v / VPP) * L::CP + (v % VPP) * 8) = RX[i];
-        }
+        constexpr int VPP = L::C / 8;
+        *reinterpret_cast<u32x4 *>(dx + (v / VPP) * L::CP + (v % VPP) * 8) = RX[i];
       }
     }
 #pragma unroll
@@ -972,48 +924,18 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
           Atom<bf16>::mma(fa[i], fb[j], acc[i][j]);
     }
   };
-  // (Measured and rejected: the consumer waves - which wait for no loads - touching one dword per 128-byte line of the
-  // group 5 iterations ahead so that the producers' real loads hit L2: 78.5 vs 69 us alone on the GPU.  64 four-byte line
-  // requests per instruction crowd the same memory queues the 16-byte loads need.)
-  // iteration i multiplies LDS buffer i & 1 (group g_i), then stages group g_{i+1} from register set (i+1) & 1 and
-  // requests group g_{i+3} into that set; group g_{i+2} stays in flight in the other set.
+  // iteration i multiplies LDS buffer i & 1 (group g_i), then stages group g_{i+1} and requests group g_{i+2}
   const long gs = gridDim.x;
   long grp = blockIdx.x;
-  if constexpr (L::PF2 != 0) {
-    if (producer) {
-      gload(R0, grp);
-      gload(R1, grp + gs);
-      swrite(R0, 0, grp);
-      gload(R0, grp + 2 * gs);
-    }
+  gload(R0, grp);
+  swrite(R0, 0, grp);
+  gload(R0, grp + gs);
+  __syncthreads();
+  for (int it = 0; grp < ngroups; grp += gs, ++it) {
+    multiply(it & 1);
+    swrite(R0, (it + 1) & 1, grp + gs);
+    gload(R0, grp + 2 * gs);
     __syncthreads();
-    for (; grp < ngroups; grp += 2 * gs) { // (roles are wave-uniform: a wave runs one branch with EXEC all ones)
-      if (consumer)
-        multiply(0);
-      if (producer) {
-        swrite(R1, 1, grp + gs);
-        gload(R1, grp + 3 * gs);
-      }
-      __syncthreads();
-      if (consumer)
-        multiply(1); // (a group past the end was staged as zeros: adds nothing)
-      if (producer) {
-        swrite(R0, 0, grp + 2 * gs);
-        gload(R0, grp + 4 * gs);
-      }
-      __syncthreads();
-    }
-  } else { // one group ahead (conv2 / conv3: a second register set would spill)
-    gload(R0, grp);
-    swrite(R0, 0, grp);
-    gload(R0, grp + gs);
-    __syncthreads();
-    for (int it = 0; grp < ngroups; grp += gs, ++it) {
-      multiply(it & 1);
-      swrite(R0, (it + 1) & 1, grp + gs);
-      gload(R0, grp + 2 * gs);
-      __syncthreads();
-    }
   }
   // ---- one slab per workgroup
   float *ow = P.slab_w + (long)blockIdx.x * L::OC * L::NJ;
@@ -1024,8 +946,7 @@ template <class L> __global__ __launch_bounds__(512) void conv_wgrad_patch_kerne
       const int m = (wm * L::MI + i) * 16 + lg * 4 + r;
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        if (consumer)
-          ow[(long)m * L::NJ + (wn * NI + j) * 16 + li] = acc[i][j][r] * P.scale;
+        ow[(long)m * L::NJ + (wn * NI + j) * 16 + li] = acc[i][j][r] * P.scale;
     }
   // bias: threads with equal tid % VPR hold the same 8 channels; ordered LDS reduction (deterministic)
   __syncthreads();
