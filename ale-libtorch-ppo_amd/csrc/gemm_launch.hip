@@ -87,7 +87,7 @@ template <int MODE, int NST> static void launch_pipe(hipStream_t s, const PipePa
   // XCD-grouped job maps apply; jobless workgroups exit at once.
   const int cus = pipe_cus() / 8 * 8, rounds = (P.njobs + cus - 1) / cus;
   const int grid = P.njobs >= cus / 4 ? std::min(cus, ((P.njobs + rounds - 1) / rounds + 7) / 8 * 8) : std::min(P.njobs, cus);
-  hipLaunchKernelGGL((gemm_pipe_kernel<MODE, NST>), dim3(grid), dim3(512), sm, s, P);
+  hipLaunchKernelGGL((gemm_pipe_kernel<MODE, NST>), dim3(grid), dim3(PIPE_THREADS), sm, s, P);
 }
 static bool fc_dma() {
   static const bool v = tune("ALEPPO_FC_DMA", 1) != 0;
