@@ -105,6 +105,12 @@ def run(args):
     if "WORLD_SIZE" in os.environ:  # one line per rank: what the launcher handed over
         log(f"rank {rank} local_rank {local_rank} world_size {world} master "
             f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}")
+    if world > 1:
+        # a rank holds the null stream, the main, weight-gradient and communication streams plus whatever RCCL and
+        # torch.distributed create; the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues,
+        # and a communication stream that lands in the main stream's queue would serialise the all-reduce behind the
+        # backward pass it is meant to overlap.  Read at runtime initialisation: set before torch loads.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch  # (first: libaleppo.so must bind to the HIP runtime torch ships, not load a second one)
     import torch.distributed as dist
     load_package().device_check(local_rank)  # fails loudly (ALEPPO_ERR_NO_DEVICE) before anything else touches a device

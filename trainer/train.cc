@@ -671,6 +671,8 @@ int main(int argc, char **argv) {
     const int world = std::max(1, env_int("WORLD_SIZE", 1)), rank = env_int("RANK", 0), local_rank = env_int("LOCAL_RANK", rank);
     if (rank < 0 || rank >= world)
       throw std::runtime_error("RANK must be in [0, WORLD_SIZE)");
+    if (world > 1) // (before the first HIP call: the runtime reads it when it initialises; see bench.py / DESIGN.md 6)
+      setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
     if (cfg.total_environments % (size_t)world)
       throw std::runtime_error("total_environments must be divisible by WORLD_SIZE");
     const size_t E = cfg.total_environments / (size_t)world, T = cfg.horizon, A = cfg.action_size; // E: THIS rank's envs
