@@ -39,13 +39,14 @@ FIELDS = dict(observations=0, actions=1, rewards=2, masks=3, logits=4, values=5,
 METRIC_FIELDS = dict(total_losses=0, clipped_losses=1, value_losses=2, entropies=3, ratio=4)
 KERNEL_CLASSES = dict(ingest=0, gae=1, head=2, adam=3, conv1_fwd=4, conv2_fwd=5, conv3_fwd=6, fc_fwd=7, fc_dgrad=8,
                       fc_wgrad=9, conv3_dgrad=10, conv3_wgrad=11, conv2_dgrad=12, conv2_wgrad=13, conv1_wgrad=14,
-                      reduce=15, infer_head=16, act_fused=17)
+                      reduce=15, infer_head=16, act_fused=17, conv_fwd=18)
 
 # every symbol include/aleppo.h declares (checked by tests/test_abi.py against the header text)
 # aleppo_set_option keys (include/aleppo.h)
 OPT_GENERIC_CONV, OPT_DEBUG_NO_PUBLISH, OPT_FORCE_COMM, OPT_SERIAL_UPDATE = 0, 1, 2, 3
 OPT_FC_PIPE, OPT_FUSED_ACT, OPT_UPDATE_GRAPH = 4, 6, 7
 OPT_GATE_TIMEOUT_MS = 9
+OPT_FUSED_FWD = 10
 
 EXPORTS = [
     "aleppo_abi_version", "aleppo_create", "aleppo_destroy", "aleppo_last_error", "aleppo_param_count",

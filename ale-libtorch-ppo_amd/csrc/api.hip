@@ -33,6 +33,7 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   Tuning t;
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
+  t.fused_fwd = flag("ALEPPO_FWD_FUSED", true);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -266,6 +267,16 @@ static const void *Pcw(const Ctx *c, ParamId id) {
 // conv stack forward for ns samples addressed by map -> c->h
 // returns the number of split-K partial slabs of h (1 unless max_parts allows the pipelined fc kernel to split)
 static int net_forward(Ctx *c, const uint32_t *obs, SampleMap map, long ns, int max_parts = 1) {
+  if (c->prec == ALEPPO_BF16 && use_patch_kernels() && tuning().fused_fwd) { // one launch: a1 / a2 are only written
+    prof_begin(c, ALEPPO_K_CONV_FWD);
+    patch_fwd_fused(c->stream, obs, map, Pcw(c, P_W1), Pf(c, P_B1), Pcw(c, P_W2), Pf(c, P_B2), Pcw(c, P_W3), Pf(c, P_B3),
+                    c->a1, c->a2, c->a3, ns);
+    prof_end(c, ALEPPO_K_CONV_FWD);
+    prof_begin(c, ALEPPO_K_FC_FWD);
+    const int parts = fc_fwd(c->stream, c->prec, c->a3, Pcw(c, P_WFC), Pf(c, P_BFC), c->h, ns, c->H, max_parts);
+    prof_end(c, ALEPPO_K_FC_FWD);
+    return parts;
+  }
   prof_begin(c, ALEPPO_K_CONV1_FWD);
   conv1_fwd(c->stream, c->prec, obs, map, Pcw(c, P_W1), Pf(c, P_B1), c->a1, ns);
   prof_end(c, ALEPPO_K_CONV1_FWD);
@@ -1671,6 +1682,8 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->tune.fc_pipe = value != 0;
   else if (option == ALEPPO_OPT_FUSED_ACT)
     c->tune.fused_act = value; // 0: never, 1: where it is faster (default), 2: always
+  else if (option == ALEPPO_OPT_FUSED_FWD)
+    c->tune.fused_fwd = value != 0;
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
   else if (option == ALEPPO_OPT_SERIAL_UPDATE)
@@ -1696,6 +1709,7 @@ extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
   case ALEPPO_OPT_SERIAL_UPDATE: *value = c->serial_update; break;
   case ALEPPO_OPT_FC_PIPE: *value = c->tune.fc_pipe; break;
   case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
+  case ALEPPO_OPT_FUSED_FWD: *value = c->tune.fused_fwd; break;
   case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
   case ALEPPO_OPT_GATE_TIMEOUT_MS: *value = (int64_t)(c->gate_timeout_ticks / 100000ull); break;
   default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");

@@ -4,6 +4,7 @@
 #include "conv_patch.hpp"
 #include "conv1_wgrad.hpp"
 #include "conv3_tile.hpp"
+#include "conv_fwd_fused.hpp"
 #include <cstdlib>
 
 namespace aleppo {
@@ -71,6 +72,30 @@ void patch_conv3_fwd(hipStream_t s, const void *a2, const void *W3, const float 
     launch_patch<LConv3FwdSmall, 8, 1>(s, P);
   else
     launch_patch<LConv3Fwd1W4, 4, 2>(s, P);
+}
+template <int ABL> static void launch_fwd_fused(hipStream_t s, const FwdFusedParams &P) {
+  static bool once = false;
+  if (!once) {
+    allow_smem(fwd_fused_kernel<ABL>, FWD_FUSED_SMEM);
+    once = true;
+  }
+  hipLaunchKernelGGL(fwd_fused_kernel<ABL>, dim3((unsigned)std::min<long>(P.ns, num_cus())), dim3(FF_NT), FWD_FUSED_SMEM, s, P);
+}
+void patch_fwd_fused(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
+                     const float *b2, const void *W3, const float *b3, void *a1, void *a2, void *a3, long ns) {
+  FwdFusedParams P{obs, map, static_cast<const bf16 *>(W1), static_cast<const bf16 *>(W2), static_cast<const bf16 *>(W3),
+                   b1,  b2,  b3, static_cast<bf16 *>(a1), static_cast<bf16 *>(a2), static_cast<bf16 *>(a3), ns};
+  // ALEPPO_FF_ABLATE: timing-only builds of the kernel with one part left out (wrong results)
+  static const int abl = std::getenv("ALEPPO_FF_ABLATE") ? std::atoi(std::getenv("ALEPPO_FF_ABLATE")) : 0;
+  switch (abl) {
+  case 1: return launch_fwd_fused<1>(s, P);
+  case 2: return launch_fwd_fused<2>(s, P);
+  case 4: return launch_fwd_fused<4>(s, P);
+  case 8: return launch_fwd_fused<8>(s, P);
+  case 16: return launch_fwd_fused<16>(s, P);
+
+  default: return launch_fwd_fused<0>(s, P);
+  }
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),

@@ -341,12 +341,17 @@ static inline int chunk_for(long Ktot, int S, int KP) {
   return (int)c;
 }
 
+// Split-K factor of the fc weight gradient.  2: 400 workgroups of 64 x 128 at H = 512, and two fp32 slabs (12.8 MB) for the
+// reduce to read.  Measured per minibatch on one box (update loop, us): B = 4096: split 2 435.7 / 437.7, 4 438.0 / 438.0,
+// 3 440.3 / 441.3, 8 444.3 / 446.8; B = 1280 (v1.yaml): split 2 232-235, split 4 241-244.
+static int fc_wgrad_split_max() { return tune("ALEPPO_FC_WGRAD_SPLIT", 2); }
+
 template <class T> static int fc_wgrad_t(hipStream_t s, const void *dh, const void *a3, float *sw, float *sb, long ns, int H) {
   using AL = DenseLoader<T>;
   using BL = DenseLoader<T>;
   constexpr int KP = Atom<T>::KT;
   static const int v = tune("ALEPPO_FC_WGRAD_TILE", 0);
-  static const int smax = tune("ALEPPO_FC_WGRAD_SPLIT", 4);
+  static const int smax = fc_wgrad_split_max();
   // S == 1: the "slab" IS the gradient tensor (caller passes G); S > 1: split-K slabs reduced by the caller
   const int S = (int)std::max<long>(1, std::min<long>(std::min(smax, MAXS_FC), ns / (4 * KP)));
   const int kc = chunk_for(ns, S, KP);
@@ -467,7 +472,7 @@ void conv2_dgrad(hipStream_t s, int prec, const void *dz2, const void *W2d, cons
   DISPATCH(prec, conv2_dgrad_t<float>(s, dz2, W2d, a1, dz1, ns), conv2_dgrad_t<bf16>(s, dz2, W2d, a1, dz1, ns));
 }
 int fc_wgrad_slices(int prec, long ns) {
-  static const int smax = tune("ALEPPO_FC_WGRAD_SPLIT", 4);
+  static const int smax = fc_wgrad_split_max();
   const int KP = prec == ALEPPO_BF16 ? Atom<bf16>::KT : Atom<float>::KT;
   return (int)std::max<long>(1, std::min<long>(std::min(smax, MAXS_FC), ns / (4 * KP)));
 }

@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 # algorithmic FLOPs per sample of each conv/linear kernel (2*MAC), SURVEY 8(d): fwd 18.69, fwd+bwd 49.52 MFLOP
-KFLOP = dict(conv1_fwd=2 * 400 * 32 * 256, conv2_fwd=2 * 81 * 64 * 512, conv3_fwd=2 * 49 * 64 * 576,
+KFLOP = dict(conv_fwd=2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576),  # the fused launch (bf16 default) ...
+             conv1_fwd=2 * 400 * 32 * 256, conv2_fwd=2 * 81 * 64 * 512, conv3_fwd=2 * 49 * 64 * 576,  # ... or these three
              fc_fwd=2 * 3136 * 512, fc_dgrad=2 * 3136 * 512, fc_wgrad=2 * 3136 * 512, conv3_dgrad=2 * 49 * 64 * 576,
              conv3_wgrad=2 * 49 * 64 * 576, conv2_dgrad=2 * 81 * 64 * 512, conv2_wgrad=2 * 81 * 64 * 512,
              conv1_wgrad=2 * 400 * 32 * 256)
@@ -39,7 +40,8 @@ def kernel_bytes(dtype):
     e = 2 if dtype == "bf16" else 4
     obs, a1, a2, a3, h = 28224, 12800 * e, 5184 * e, 3136 * e, 512 * 4
     dh = 512 * e
-    return dict(conv1_fwd=obs + a1, conv2_fwd=a1 + a2, conv3_fwd=a2 + a3, fc_fwd=a3 + h, fc_dgrad=dh + 2 * a3,
+    return dict(conv_fwd=obs + a1 + a2 + a3,  # a1 / a2 / a3 written once for the backward pass, nothing read back
+                conv1_fwd=obs + a1, conv2_fwd=a1 + a2, conv3_fwd=a2 + a3, fc_fwd=a3 + h, fc_dgrad=dh + 2 * a3,
                 fc_wgrad=dh + a3, conv3_dgrad=a3 + 2 * a2, conv3_wgrad=a3 + a2, conv2_dgrad=a2 + 2 * a1,
                 conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs)
 
@@ -274,7 +276,7 @@ def run(args):
         # dominant kernel = the longest one on the update's CRITICAL PATH (main stream: forward chain, dgrad chain, conv1
         # wgrad).  The weight-gradient kernels of the second stream run in the main stream's shadow and stretch with it
         # (fc wgrad: 38 us alone, 72 us beside fc dgrad + conv3 dgrad): their timed-region durations are not a cost.
-        main_stream = ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv2_dgrad", "conv1_wgrad")
+        main_stream = ("conv_fwd", "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv2_dgrad", "conv1_wgrad")
         dom = max((k for k in table if k in main_stream), key=lambda k: trn[k][0] * trn[k][1])
         d = table[dom]
         # HBM traffic of the dominant kernel: recorded by `tests/tools/pmc_traffic.py` (rocprofv3 --pmc passes cannot run
@@ -302,8 +304,8 @@ def run(args):
                                              f"passes, FETCH x2 gfx950 correction; kernel sources {stamp})") if pmc
                         else None, kernel_source_sha16=stamp)
         upd_ms = sum(v[0] * v[1] for v in trn.values())
-        roofline["update_all_kernels_TFLOPs"] = round(sum(KFLOP.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e12, 2)
-        roofline["update_all_kernels_GBps"] = round(sum(KB.values()) * B * epochs * M / (upd_ms * 1e-3) / 1e9, 1)
+        roofline["update_all_kernels_TFLOPs"] = round(sum(KFLOP[k] for k in table) * B * epochs * M / (upd_ms * 1e-3) / 1e12, 2)
+        roofline["update_all_kernels_GBps"] = round(sum(KB[k] for k in table) * B * epochs * M / (upd_ms * 1e-3) / 1e9, 1)
         roofline["update_kernels"] = table
         iso_tab = {}
         for k in KFLOP:  # the same table with every kernel running alone (ALEPPO_OPT_SERIAL_UPDATE)

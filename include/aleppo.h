@@ -302,7 +302,8 @@ typedef enum {
   ALEPPO_K_REDUCE = 15,     /* split-K slab reduction */
   ALEPPO_K_INFER_HEAD = 16, /* action head + sampling */
   ALEPPO_K_ACT_FUSED = 17,  /* frame ingest + conv1-3 of the acting batch in one launch (aleppo_step, bf16) */
-  ALEPPO_K_COUNT = 18
+  ALEPPO_K_CONV_FWD = 18,   /* conv1 -> conv2 -> conv3 of the update's forward pass in one launch (bf16) */
+  ALEPPO_K_COUNT = 19
 } aleppo_kernel_class;
 int aleppo_profile_enable(aleppo_ctx *ctx, int on);
 int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);
@@ -322,6 +323,9 @@ typedef enum {
                                       is faster (default: given 84x84 frames, raw pairs in mapped host memory), 2 always */
   ALEPPO_OPT_GATE_TIMEOUT_MS = 9,  /* exit condition of the slot-ahead gate in milliseconds (default 120 000; also the
                                       environment variable ALEPPO_GATE_TIMEOUT_MS at aleppo_create) */
+  ALEPPO_OPT_FUSED_FWD = 10,       /* 0: the update's forward convolutions as three launches instead of the fused
+                                      conv1 -> conv2 -> conv3 kernel (bf16; same bits either way: A/B, parity tests; also
+                                      the environment variable ALEPPO_FWD_FUSED at aleppo_create) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */

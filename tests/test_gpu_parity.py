@@ -319,6 +319,36 @@ def test_bf16_patch_kernels_match_generic_kernels(pkg, N):
     np.testing.assert_allclose(g0 / c0, w["last_grads"] / cw, atol=3e-2 * np.abs(w["last_grads"] / cw).max())
 
 
+@pytest.mark.parametrize("N", [8, 200, 1400, 4104])
+def test_bf16_fused_forward_is_bit_identical_to_the_three_launches(pkg, N):
+    """csrc/conv_fwd_fused.hpp (conv1 -> conv2 -> conv3 of a sample in one workgroup, a1 / a2 handed over in LDS; hot loop in
+    inline assembly with hand-counted waits) against the three sample-stationary forward launches it replaces
+    (ALEPPO_OPT_FUSED_FWD = 0): the same MFMA k-order per output, so logits, values, losses, every gradient and the
+    updated parameters must be IDENTICAL bits.  A stale fragment, an early `vmcnt` on the prefetched stack or a wrong a1 /
+    a2 copy for the backward pass shows up here.  N = 8: fewer samples than workgroups; 200 / 1400: 100- / 700-sample
+    minibatches (ragged last round of the persistent loop); 4104: 2052 samples = 8 full rounds + 4 on a 256-CU part."""
+    H, A, M = 512, 6, 2
+    params = hf.fill_params(720, H, A)
+    obs = hf.hf_bytes(721, (N, 4, 84, 84))
+    actions = (hf.hf_u32(722, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(723, (N, A), -1, 1))
+    adv, ret = hf.hf_range(724, (N,), -1, 1), hf.hf_range(725, (N,), -1, 1)
+    masks = (hf.hf_unit(726, N) >= np.float32(0.1)).astype(np.uint8)
+    res = {}
+    for fused in (1, 0):
+        eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
+        eng.set_option(pkg.OPT_FUSED_FWD, fused)
+        assert eng.get_option(pkg.OPT_FUSED_FWD) == fused
+        eng.load_params(params)
+        logits, values = eng.forward(obs[:min(N, 333)])
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m = eng.train(2.5e-4, 2, M)
+        res[fused] = (logits, values, m["loss"], m["grad_norm"], eng.export_grads(), eng.export_params())
+        eng.close()
+    for a, b, what in zip(res[1], res[0], ("logits", "values", "loss", "grad_norm", "grads", "params")):
+        assert np.array_equal(np.asarray(a), np.asarray(b)), what
+
+
 @pytest.mark.parametrize("N,M", [(8, 2), (8, 1), (24, 2), (264, 1), (520, 1), (1032, 1), (3080, 1)])
 def test_bf16_conv1_weight_gradient_ragged_sizes(pkg, N, M):
     """conv1's weight / bias gradient from the tap-shift kernel (csrc/conv1_wgrad.hpp: half-sample groups dealt to
