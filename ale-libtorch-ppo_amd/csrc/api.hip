@@ -34,7 +34,6 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fused_fwd = flag("ALEPPO_FWD_FUSED", true);
-  t.fused_bwd3 = flag("ALEPPO_BWD3_FUSED", false);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -1223,7 +1222,6 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
   const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
-  const bool bwd3_fused = c->tune.fused_bwd3 && prec == ALEPPO_BF16 && use_patch_kernels();
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
   // (Tried in round 3, tests/tools/forkbench.hip: in isolation an event record + wait costs the pair of streams ~12 us
   // per dependency, a one-wave signal kernel + a one-wave gate kernel on a device word ~3 us.  In the update it changes
@@ -1290,20 +1288,13 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         NCCLCHK(c, ncclAllReduce(c->G, c->G, L.bucket0_end, ncclFloat, ncclSum, comm, c->comm_stream));
         HIPCHK(c, hipEventRecord(c->ev_comm0, c->comm_stream));
       }
-      int S3 = 0;
-      if (bwd3_fused) { // conv3's dgrad and wgrad: one launch on the main stream, dz3 / a2 staged once (conv3_bwd_fused.hpp)
-        prof_begin(c, ALEPPO_K_CONV3_DGRAD);
-        S3 = patch_conv3_bwd_fused(s, c->dz3, c->a2, c->W3d, c->dz2, sW3, sB3, B);
-        prof_end(c, ALEPPO_K_CONV3_DGRAD);
-      } else {
       HIPCHK(c, fork(c->ev_dz3)); // dz3 is ready
       prof_begin(c, ALEPPO_K_CONV3_DGRAD);
       conv3_dgrad(s, prec, c->dz3, c->W3d, c->a2, c->dz2, B);
       prof_end(c, ALEPPO_K_CONV3_DGRAD);
       prof_begin(c, ALEPPO_K_CONV3_WGRAD, sw);
-      S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
+      const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
       prof_end(c, ALEPPO_K_CONV3_WGRAD, sw);
-      }
       HIPCHK(c, fork(c->ev_dz2)); // dz2 is ready
       prof_begin(c, ALEPPO_K_CONV2_DGRAD);
       conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
@@ -1693,8 +1684,6 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->tune.fused_act = value; // 0: never, 1: where it is faster (default), 2: always
   else if (option == ALEPPO_OPT_FUSED_FWD)
     c->tune.fused_fwd = value != 0;
-  else if (option == ALEPPO_OPT_FUSED_BWD)
-    c->tune.fused_bwd3 = value != 0;
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
   else if (option == ALEPPO_OPT_SERIAL_UPDATE)
@@ -1721,7 +1710,6 @@ extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
   case ALEPPO_OPT_FC_PIPE: *value = c->tune.fc_pipe; break;
   case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
   case ALEPPO_OPT_FUSED_FWD: *value = c->tune.fused_fwd; break;
-  case ALEPPO_OPT_FUSED_BWD: *value = c->tune.fused_bwd3; break;
   case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
   case ALEPPO_OPT_GATE_TIMEOUT_MS: *value = (int64_t)(c->gate_timeout_ticks / 100000ull); break;
   default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");

@@ -5,7 +5,6 @@
 #include "conv1_wgrad.hpp"
 #include "conv3_tile.hpp"
 #include "conv_fwd_fused.hpp"
-#include "conv3_bwd_fused.hpp"
 #include <cstdlib>
 
 namespace aleppo {
@@ -97,30 +96,6 @@ void patch_fwd_fused(hipStream_t s, const uint32_t *obs, SampleMap map, const vo
 
   default: return launch_fwd_fused<0>(s, P);
   }
-}
-template <int ABL> static void launch_conv3_bwd(hipStream_t s, const Conv3BwdParams &P, int grid) {
-  static bool once = false;
-  if (!once) {
-    allow_smem(conv3_bwd_fused_kernel<ABL>, c3b::SMEM);
-    once = true;
-  }
-  hipLaunchKernelGGL(conv3_bwd_fused_kernel<ABL>, dim3(grid), dim3(c3b::NT), c3b::SMEM, s, P);
-}
-int patch_conv3_bwd_fused(hipStream_t s, const void *dz3, const void *a2, const void *W3d, void *dz2, float *sw, float *sb,
-                          long ns) {
-  Conv3BwdParams P{static_cast<const bf16 *>(dz3), static_cast<const bf16 *>(a2), static_cast<const bf16 *>(W3d),
-                   static_cast<bf16 *>(dz2), sw, sb, ns};
-  static const int cap = std::getenv("ALEPPO_B3_GRID") ? std::atoi(std::getenv("ALEPPO_B3_GRID")) : num_cus();
-  const int grid = (int)std::min<long>(ns, std::min(std::min(num_cus(), MAXS_C3), cap));
-  static const int abl = std::getenv("ALEPPO_B3_ABLATE") ? std::atoi(std::getenv("ALEPPO_B3_ABLATE")) : 0;
-  switch (abl) {
-  case 1: launch_conv3_bwd<1>(s, P, grid); break;
-  case 2: launch_conv3_bwd<2>(s, P, grid); break;
-  case 4: launch_conv3_bwd<4>(s, P, grid); break;
-  case 7: launch_conv3_bwd<7>(s, P, grid); break;
-  default: launch_conv3_bwd<0>(s, P, grid); break;
-  }
-  return grid;
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),

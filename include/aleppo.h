@@ -326,8 +326,6 @@ typedef enum {
   ALEPPO_OPT_FUSED_FWD = 10,       /* 0: the update's forward convolutions as three launches instead of the fused
                                       conv1 -> conv2 -> conv3 kernel (bf16; same bits either way: A/B, parity tests; also
                                       the environment variable ALEPPO_FWD_FUSED at aleppo_create) */
-  ALEPPO_OPT_FUSED_BWD = 11,       /* 0: conv3's data gradient and weight gradient as two launches on two streams instead
-                                      of the fused kernel (bf16; A/B, parity tests; environment: ALEPPO_BWD3_FUSED) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */

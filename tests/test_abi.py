@@ -105,7 +105,7 @@ def test_option_and_location_constants_match_the_header(pkg):
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aleppo.h")).read(), flags=re.S)
     for name, val in (("ALEPPO_OPT_GENERIC_CONV", pkg.OPT_GENERIC_CONV), ("ALEPPO_OPT_FC_PIPE", pkg.OPT_FC_PIPE),
                       ("ALEPPO_OPT_FUSED_ACT", pkg.OPT_FUSED_ACT), ("ALEPPO_OPT_GATE_TIMEOUT_MS", pkg.OPT_GATE_TIMEOUT_MS),
-                      ("ALEPPO_OPT_UPDATE_GRAPH", pkg.OPT_UPDATE_GRAPH), ("ALEPPO_OPT_FUSED_FWD", pkg.OPT_FUSED_FWD), ("ALEPPO_OPT_FUSED_BWD", pkg.OPT_FUSED_BWD),
+                      ("ALEPPO_OPT_UPDATE_GRAPH", pkg.OPT_UPDATE_GRAPH), ("ALEPPO_OPT_FUSED_FWD", pkg.OPT_FUSED_FWD),
                       ("ALEPPO_OPT_SERIAL_UPDATE", pkg.OPT_SERIAL_UPDATE), ("ALEPPO_OPT_FORCE_COMM", pkg.OPT_FORCE_COMM),
                       ("ALEPPO_HOST_MAPPED", pkg.HOST_MAPPED), ("ALEPPO_ROLLOUT_FP16", pkg.ROLLOUT_FP16),
                       ("ALEPPO_ABI_VERSION", pkg.ABI_VERSION)):
