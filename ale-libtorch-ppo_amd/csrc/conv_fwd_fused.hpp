@@ -205,6 +205,7 @@ __global__ __launch_bounds__(FF_NT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     for (int i = 0; i < NR; ++i)
       asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(R[i]) : "v"(src + min(tid + FF_NT * i, NXV - 1)) : "memory");
   };
+  load_obs(n); // (first: its round trip to HBM runs under the weight set-up below)
   { // ---- the three layers' weights: one coalesced copy per workgroup -> padded LDS image -> this wave's two atoms
     auto img_off = [](int v, int vpr, int pitch) { return (v / vpr) * pitch + (v % vpr) * 16; };
     W1.load_bias(P.b1, wave, lane);
@@ -239,7 +240,6 @@ __global__ __launch_bounds__(FF_NT) __attribute__((amdgpu_waves_per_eu(1, 1))) v
     W3.load_lds(smem, wave, lane);
     __syncthreads();
   }
-  load_obs(n);
   asm volatile("s_waitcnt vmcnt(0)"
                : "+a"(R[0]), "+a"(R[1]), "+a"(R[2]), "+a"(R[3]), "+a"(R[4]), "+a"(R[5]), "+a"(R[6])::"memory");
   auto pk = [](uint32_t lo, uint32_t hi) { return pack_u8_pair_bf16(lo, hi); };
