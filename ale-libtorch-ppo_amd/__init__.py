@@ -47,6 +47,7 @@ OPT_GENERIC_CONV, OPT_DEBUG_NO_PUBLISH, OPT_FORCE_COMM, OPT_SERIAL_UPDATE = 0, 1
 OPT_FC_PIPE, OPT_FUSED_ACT, OPT_UPDATE_GRAPH = 4, 6, 7
 OPT_GATE_TIMEOUT_MS = 9
 OPT_FUSED_FWD = 10
+OPT_FUSED_BWD = 11
 
 EXPORTS = [
     "aleppo_abi_version", "aleppo_create", "aleppo_destroy", "aleppo_last_error", "aleppo_param_count",

@@ -34,6 +34,7 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fused_fwd = flag("ALEPPO_FWD_FUSED", true);
+  t.fused_bwd = flag("ALEPPO_BWD_FUSED", false);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -1222,6 +1223,7 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
   const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
+  const bool bwd_fused = c->tune.fused_bwd && prec == ALEPPO_BF16 && use_patch_kernels();
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
   // (Tried in round 3, tests/tools/forkbench.hip: in isolation an event record + wait costs the pair of streams ~12 us
   // per dependency, a one-wave signal kernel + a one-wave gate kernel on a device word ~3 us.  In the update it changes
@@ -1295,20 +1297,43 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
       prof_begin(c, ALEPPO_K_CONV3_WGRAD, sw);
       const int S3 = conv3_wgrad(sw, prec, c->dz3, c->a2, sW3, sB3, B);
       prof_end(c, ALEPPO_K_CONV3_WGRAD, sw);
+      int S2 = 0, S1 = 0, nseg = 0;
+      ReduceSeg segs[10];
+      if (bwd_fused) {
+        // conv2 dgrad + conv2 wgrad + conv1 wgrad in ONE launch on the main stream (conv_bwd_fused.hpp: dz1 never leaves the
+        // CU).  Meanwhile the weight-gradient stream reduces the slab groups that are complete (conv3, heads + fc).
+        segs[nseg++] = ReduceSeg{sW3, S3, 64 * 576, (long)L.off[P_W3]};
+        segs[nseg++] = ReduceSeg{sB3, S3, 64, (long)L.off[P_B3]};
+        if (!early0)
+          for (int i = 0; i < nseg0; ++i)
+            segs[nseg++] = segs0[i];
+        if (two) {
+          prof_begin(c, ALEPPO_K_REDUCE, sw);
+          launch_reduce_slabs(sw, segs, nseg, c->G);
+          prof_end(c, ALEPPO_K_REDUCE, sw);
+          nseg = 0;
+        }
+        prof_begin(c, ALEPPO_K_CONV2_DGRAD);
+        S2 = S1 = patch_conv_bwd_fused(s, c->dz2, c->a1, c->obs, map, c->W2d, sW2, sB2, sW1, sB1, B);
+        prof_end(c, ALEPPO_K_CONV2_DGRAD);
+        segs[nseg++] = ReduceSeg{sW2, S2, 64 * 512, (long)L.off[P_W2]};
+        segs[nseg++] = ReduceSeg{sB2, S2, 64, (long)L.off[P_B2]};
+      } else {
       HIPCHK(c, fork(c->ev_dz2)); // dz2 is ready
       prof_begin(c, ALEPPO_K_CONV2_DGRAD);
       conv2_dgrad(s, prec, c->dz2, c->W2d, c->a1, c->dz1, B);
       prof_end(c, ALEPPO_K_CONV2_DGRAD);
       prof_begin(c, ALEPPO_K_CONV2_WGRAD, sw);
-      const int S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
+      S2 = conv2_wgrad(sw, prec, c->dz2, c->a1, sW2, sB2, B);
       prof_end(c, ALEPPO_K_CONV2_WGRAD, sw);
       // conv1 wgrad is the last link of the dgrad chain and runs alone on s: meanwhile the wgrad stream reduces every
       // slab group that is already complete (reducing them AFTER conv1 wgrad on the main stream instead measured slower:
       // 7.89-7.96 vs 7.77 ms per update) (conv3, conv2 and - on one GPU - heads + fc); only conv1's slabs are left
       // for the reduce after the join.
-      ReduceSeg segs[10] = {{sW3, S3, 64 * 576, (long)L.off[P_W3]}, {sB3, S3, 64, (long)L.off[P_B3]},
-                            {sW2, S2, 64 * 512, (long)L.off[P_W2]}, {sB2, S2, 64, (long)L.off[P_B2]}};
-      int nseg = 4;
+      segs[nseg++] = ReduceSeg{sW3, S3, 64 * 576, (long)L.off[P_W3]};
+      segs[nseg++] = ReduceSeg{sB3, S3, 64, (long)L.off[P_B3]};
+      segs[nseg++] = ReduceSeg{sW2, S2, 64 * 512, (long)L.off[P_W2]};
+      segs[nseg++] = ReduceSeg{sB2, S2, 64, (long)L.off[P_B2]};
       if (!early0)
         for (int i = 0; i < nseg0; ++i)
           segs[nseg++] = segs0[i];
@@ -1319,8 +1344,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
         nseg = 0;
       }
       prof_begin(c, ALEPPO_K_CONV1_WGRAD);
-      const int S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
+      S1 = conv1_wgrad(s, prec, c->dz1, c->obs, map, sW1, sB1, B);
       prof_end(c, ALEPPO_K_CONV1_WGRAD);
+      }
       if (two) { // join: sumsq / Adam read the whole gradient
         HIPCHK(c, hipEventRecord(c->ev_wg, sw));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_wg, 0));
@@ -1684,6 +1710,8 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
     c->tune.fused_act = value; // 0: never, 1: where it is faster (default), 2: always
   else if (option == ALEPPO_OPT_FUSED_FWD)
     c->tune.fused_fwd = value != 0;
+  else if (option == ALEPPO_OPT_FUSED_BWD)
+    c->tune.fused_bwd = value != 0;
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
   else if (option == ALEPPO_OPT_SERIAL_UPDATE)
@@ -1710,6 +1738,7 @@ extern "C" int aleppo_get_option(aleppo_ctx *c, int option, int64_t *value) {
   case ALEPPO_OPT_FC_PIPE: *value = c->tune.fc_pipe; break;
   case ALEPPO_OPT_FUSED_ACT: *value = c->tune.fused_act; break;
   case ALEPPO_OPT_FUSED_FWD: *value = c->tune.fused_fwd; break;
+  case ALEPPO_OPT_FUSED_BWD: *value = c->tune.fused_bwd; break;
   case ALEPPO_OPT_UPDATE_GRAPH: *value = c->graph_replays; break;
   case ALEPPO_OPT_GATE_TIMEOUT_MS: *value = (int64_t)(c->gate_timeout_ticks / 100000ull); break;
   default: return set_err(c, ALEPPO_ERR_INVALID_ARGUMENT, "unknown option");

@@ -61,6 +61,7 @@ struct Tuning {
   bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
   bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
   bool fused_fwd = true;      // the update's conv1 -> conv2 -> conv3 forward as one launch (conv_fwd_fused.hpp)
+  bool fused_bwd = false;     // conv2 dgrad + conv2 wgrad + conv1 wgrad as one launch (conv_bwd_fused.hpp)
   int fused_act = 1;          // frame ingest fused in front of the acting convolutions: 0 never, 1 where faster, 2 always
 };
 const Tuning &tuning();
@@ -297,6 +298,8 @@ void patch_conv2_dgrad(hipStream_t s, const void *dz2, const void *W2d, const vo
 // a new 84x84 frame / raw frame pair (fused frame ingest: see ActIngestParams in conv_patch.hpp)
 void patch_fwd_fused(hipStream_t s, const uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
                      const float *b2, const void *W3, const float *b3, void *a1, void *a2, void *a3, long ns);
+int patch_conv_bwd_fused(hipStream_t s, const void *dz2, const void *a1, const uint32_t *obs, SampleMap map, const void *W2d,
+                         float *sw2, float *sb2, float *sw1, float *sb1, long ns);
 void patch_act_convs(hipStream_t s, uint32_t *obs, SampleMap map, const void *W1, const float *b1, const void *W2,
                      const float *b2, const void *W3, const float *b3, void *a3, long ns, int ingest_mode = 0,
                      const uint8_t *frames = nullptr, const uint8_t *lut = nullptr, const StartBits *sbits = nullptr,

@@ -5,6 +5,7 @@
 #include "conv1_wgrad.hpp"
 #include "conv3_tile.hpp"
 #include "conv_fwd_fused.hpp"
+#include "conv_bwd_fused.hpp"
 #include <cstdlib>
 
 namespace aleppo {
@@ -96,6 +97,32 @@ void patch_fwd_fused(hipStream_t s, const uint32_t *obs, SampleMap map, const vo
 
   default: return launch_fwd_fused<0>(s, P);
   }
+}
+template <int ABL> static void launch_conv_bwd(hipStream_t s, const ConvBwdParams &P, int grid) {
+  static bool once = false;
+  if (!once) {
+    allow_smem(conv_bwd_fused_kernel<ABL>, cb::SMEM);
+    once = true;
+  }
+  hipLaunchKernelGGL(conv_bwd_fused_kernel<ABL>, dim3(grid), dim3(cb::NT), cb::SMEM, s, P);
+}
+int patch_conv_bwd_fused(hipStream_t s, const void *dz2, const void *a1, const uint32_t *obs, SampleMap map, const void *W2d,
+                         float *sw2, float *sb2, float *sw1, float *sb1, long ns) {
+  ConvBwdParams P{static_cast<const bf16 *>(dz2), static_cast<const bf16 *>(a1), static_cast<const bf16 *>(W2d), obs, map,
+                  sw2, sb2, sw1, sb1, ns, 1.0f / 255.0f};
+  const int grid = (int)std::min<long>(ns, std::min(num_cus(), std::min(MAXS_C1, MAXS_C2)));
+  // ALEPPO_CB_ABLATE: timing-only builds of the kernel with one part left out (wrong results)
+  static const int abl = std::getenv("ALEPPO_CB_ABLATE") ? std::atoi(std::getenv("ALEPPO_CB_ABLATE")) : 0;
+  switch (abl) {
+  case 1: launch_conv_bwd<1>(s, P, grid); break;
+  case 2: launch_conv_bwd<2>(s, P, grid); break;
+  case 4: launch_conv_bwd<4>(s, P, grid); break;
+  case 8: launch_conv_bwd<8>(s, P, grid); break;
+  case 16: launch_conv_bwd<16>(s, P, grid); break;
+  case 31: launch_conv_bwd<31>(s, P, grid); break;
+  default: launch_conv_bwd<0>(s, P, grid); break;
+  }
+  return grid;
 }
 void patch_conv3_dgrad(hipStream_t s, const void *dz3, const void *W3d, const void *a2, void *dz2, long ns) {
   PatchParams P{dz3, static_cast<const bf16 *>(W3d), nullptr, static_cast<const bf16 *>(a2), static_cast<bf16 *>(dz2),

@@ -332,6 +332,25 @@ def run(args):
             head_GBps=round((97 + 2 * 512 * 4) * B / (trn["head"][0] * 1e-3) / 1e9, 1))
         roofline["phase_wall_ms"] = {k: round(v, 3) for k, v in phase.items()}
 
+    # ---- the opt-in fused tail of the backward pass (conv2 dgrad + conv2 wgrad + conv1 wgrad in one launch,
+    # ALEPPO_OPT_FUSED_BWD; csrc/conv_bwd_fused.hpp): the same update with it on and off, alternating, same process
+    fused_bwd = None
+    if rank == 0 and world == 1 and args.dtype == "bf16" and hasattr(pkg, "OPT_FUSED_BWD"):
+        t_on, t_off = [], []
+        for rep in range(4):
+            for on, acc in ((1, t_on), (0, t_off)):
+                eng.set_option(pkg.OPT_FUSED_BWD, on)
+                eng.train(2.5e-4, epochs, M)
+                eng.synchronize()
+                t0 = time.perf_counter()
+                eng.train(2.5e-4, epochs, M)
+                eng.synchronize()
+                acc.append((time.perf_counter() - t0) * 1e3)
+        eng.set_option(pkg.OPT_FUSED_BWD, 0)
+        fused_bwd = dict(update_ms=round(sorted(t_on)[len(t_on) // 2], 3), update_ms_default=round(sorted(t_off)[len(t_off) // 2], 3),
+                         note="update wall time with the fused backward tail on / off (median of 4, alternating); it moves "
+                              "262 instead of 619 MB per minibatch for the three kernels it replaces (DESIGN.md 4e)")
+
     # ---- the SAME workload with the frames where a host emulator leaves them (rollout.cc:325-326): page-locked host
     # memory the ingest kernel reads in place over PCIe (ALEPPO_HOST_MAPPED).  Reported beside `value`, never as it.
     host_legs = None
@@ -413,6 +432,7 @@ def run(args):
             "roofline": roofline, "cpu_baseline": cpu,
             "frames_84_hbm": (host_legs or {}).pop("frames_84_hbm", None), "host_frames": host_legs,
             "vs_reference_published_v1_26289": round(value / 26289.0, 2), "v1_shape": v1,
+            "fused_bwd_option": fused_bwd,
             "last_loss": last_loss, "last_grad_norm": last_norm,
         }
         print(json.dumps(out))

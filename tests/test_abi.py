@@ -98,14 +98,15 @@ def test_bench_spawns_one_rank_per_gpu_with_the_launcher_environment():
     assert "spawning:" in out and "--nproc-per-node=2" in out
     for rank in (0, 1):
         assert f"rank {rank} local_rank {rank} world_size 2 master 127.0.0.1:29531" in out, out[-3000:]
-    assert out.count("no CPU fallback") >= 2, out[-3000:]
+    # (the launcher terminates the other rank as soon as the first one has failed: at least one of them gets to say it)
+    assert out.count("no CPU fallback") >= 1, out[-3000:]
 
 
 def test_option_and_location_constants_match_the_header(pkg):
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aleppo.h")).read(), flags=re.S)
     for name, val in (("ALEPPO_OPT_GENERIC_CONV", pkg.OPT_GENERIC_CONV), ("ALEPPO_OPT_FC_PIPE", pkg.OPT_FC_PIPE),
                       ("ALEPPO_OPT_FUSED_ACT", pkg.OPT_FUSED_ACT), ("ALEPPO_OPT_GATE_TIMEOUT_MS", pkg.OPT_GATE_TIMEOUT_MS),
-                      ("ALEPPO_OPT_UPDATE_GRAPH", pkg.OPT_UPDATE_GRAPH), ("ALEPPO_OPT_FUSED_FWD", pkg.OPT_FUSED_FWD),
+                      ("ALEPPO_OPT_UPDATE_GRAPH", pkg.OPT_UPDATE_GRAPH), ("ALEPPO_OPT_FUSED_FWD", pkg.OPT_FUSED_FWD), ("ALEPPO_OPT_FUSED_BWD", pkg.OPT_FUSED_BWD),
                       ("ALEPPO_OPT_SERIAL_UPDATE", pkg.OPT_SERIAL_UPDATE), ("ALEPPO_OPT_FORCE_COMM", pkg.OPT_FORCE_COMM),
                       ("ALEPPO_HOST_MAPPED", pkg.HOST_MAPPED), ("ALEPPO_ROLLOUT_FP16", pkg.ROLLOUT_FP16),
                       ("ALEPPO_ABI_VERSION", pkg.ABI_VERSION)):

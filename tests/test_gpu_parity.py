@@ -349,6 +349,45 @@ def test_bf16_fused_forward_is_bit_identical_to_the_three_launches(pkg, N):
         assert np.array_equal(np.asarray(a), np.asarray(b)), what
 
 
+@pytest.mark.parametrize("N,A", [(8, 6), (200, 6), (1400, 4), (4104, 18)])
+def test_bf16_fused_backward_matches_the_three_launches(pkg, N, A):
+    """csrc/conv_bwd_fused.hpp (opt-in, ALEPPO_OPT_FUSED_BWD: conv2 dgrad + conv2 wgrad + conv1 wgrad of a sample in one
+    workgroup, dz1 never leaves the CU) against the three launches of the default schedule: dz1 is the same bits, so the
+    gradients differ only by the fp32 summation order of the weight-gradient slabs (other sample -> workgroup assignment):
+    every tensor to 1e-6 relative L2, losses and norm to 1e-6, parameters after two updates to 1e-6 absolute.  N = 8: fewer
+    samples than workgroups; 200 / 1400: 100- / 700-sample minibatches (ragged last round); 4104: 8 full rounds + 4."""
+    H, M = 512, 2
+    params = hf.fill_params(730, H, A)
+    obs = hf.hf_bytes(731, (N, 4, 84, 84))
+    actions = (hf.hf_u32(732, N) % np.uint32(A)).astype(np.int64)
+    old_lp = orc.log_softmax(hf.hf_range(733, (N, A), -1, 1))
+    adv, ret = hf.hf_range(734, (N,), -1, 1), hf.hf_range(735, (N,), -1, 1)
+    masks = (hf.hf_unit(736, N) >= np.float32(0.1)).astype(np.uint8)
+    res = {}
+    for fused in (1, 0):
+        eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
+        eng.set_option(pkg.OPT_FUSED_BWD, fused)
+        assert eng.get_option(pkg.OPT_FUSED_BWD) == fused
+        eng.load_params(params)
+        eng.set_batch(obs, actions, old_lp, adv, ret, masks)
+        m1 = eng.train(2.5e-4, 1, 1)  # one minibatch: the exported gradients of both runs belong to identical parameters
+        g = eng.export_grads()
+        m2 = eng.train(2.5e-4, 1, M)
+        res[fused] = (m1["loss"], m1["grad_norm"], g, m2["loss"], eng.export_params())
+        eng.close()
+    (l1, n1, g1, k1, p1), (l0, n0, g0, k0, p0) = res[1], res[0]
+    assert np.array_equal(l1, l0)  # the forward pass is untouched
+    np.testing.assert_allclose(n1, n0, rtol=1e-6)
+    o = 0
+    for name, sz in (("w1", 32 * 4 * 8 * 8), ("b1", 32), ("w2", 64 * 32 * 16), ("b2", 64), ("w3", 64 * 64 * 9), ("b3", 64)):
+        a, b = g1[o:o + sz], g0[o:o + sz]
+        assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b) + 1e-12, name
+        o += sz
+    assert np.linalg.norm(g1 - g0) <= 1e-6 * np.linalg.norm(g0)
+    np.testing.assert_allclose(k1, k0, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(p1, p0, atol=1e-6)
+
+
 @pytest.mark.parametrize("N,M", [(8, 2), (8, 1), (24, 2), (264, 1), (520, 1), (1032, 1), (3080, 1)])
 def test_bf16_conv1_weight_gradient_ragged_sizes(pkg, N, M):
     """conv1's weight / bias gradient from the tap-shift kernel (csrc/conv1_wgrad.hpp: half-sample groups dealt to
