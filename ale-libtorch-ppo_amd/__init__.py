@@ -39,7 +39,7 @@ FIELDS = dict(observations=0, actions=1, rewards=2, masks=3, logits=4, values=5,
 METRIC_FIELDS = dict(total_losses=0, clipped_losses=1, value_losses=2, entropies=3, ratio=4)
 KERNEL_CLASSES = dict(ingest=0, gae=1, head=2, adam=3, conv1_fwd=4, conv2_fwd=5, conv3_fwd=6, fc_fwd=7, fc_dgrad=8,
                       fc_wgrad=9, conv3_dgrad=10, conv3_wgrad=11, conv2_dgrad=12, conv2_wgrad=13, conv1_wgrad=14,
-                      reduce=15, infer_head=16, act_fused=17, conv_fwd=18)
+                      reduce=15, infer_head=16, act_fused=17, conv_fwd=18, conv_bwd=19)
 
 # every symbol include/aleppo.h declares (checked by tests/test_abi.py against the header text)
 # aleppo_set_option keys (include/aleppo.h)

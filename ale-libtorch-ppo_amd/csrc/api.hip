@@ -34,7 +34,7 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fused_fwd = flag("ALEPPO_FWD_FUSED", true);
-  t.fused_bwd = flag("ALEPPO_BWD_FUSED", false);
+  t.fused_bwd = flag("ALEPPO_BWD_FUSED", true);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -1313,9 +1313,9 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
           prof_end(c, ALEPPO_K_REDUCE, sw);
           nseg = 0;
         }
-        prof_begin(c, ALEPPO_K_CONV2_DGRAD);
+        prof_begin(c, ALEPPO_K_CONV_BWD);
         S2 = S1 = patch_conv_bwd_fused(s, c->dz2, c->a1, c->obs, map, c->W2d, sW2, sB2, sW1, sB1, B);
-        prof_end(c, ALEPPO_K_CONV2_DGRAD);
+        prof_end(c, ALEPPO_K_CONV_BWD);
         segs[nseg++] = ReduceSeg{sW2, S2, 64 * 512, (long)L.off[P_W2]};
         segs[nseg++] = ReduceSeg{sB2, S2, 64, (long)L.off[P_B2]};
       } else {

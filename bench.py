@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 # algorithmic FLOPs per sample of each conv/linear kernel (2*MAC), SURVEY 8(d): fwd 18.69, fwd+bwd 49.52 MFLOP
-KFLOP = dict(conv_fwd=2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576),  # the fused launch (bf16 default) ...
+KFLOP = dict(conv_bwd=2 * (2 * 81 * 64 * 512 + 400 * 32 * 256),  # conv2 dgrad + conv2 wgrad + conv1 wgrad, one launch (bf16 default)
+             conv_fwd=2 * (400 * 32 * 256 + 81 * 64 * 512 + 49 * 64 * 576),  # the fused launch (bf16 default) ...
              conv1_fwd=2 * 400 * 32 * 256, conv2_fwd=2 * 81 * 64 * 512, conv3_fwd=2 * 49 * 64 * 576,  # ... or these three
              fc_fwd=2 * 3136 * 512, fc_dgrad=2 * 3136 * 512, fc_wgrad=2 * 3136 * 512, conv3_dgrad=2 * 49 * 64 * 576,
              conv3_wgrad=2 * 49 * 64 * 576, conv2_dgrad=2 * 81 * 64 * 512, conv2_wgrad=2 * 81 * 64 * 512,
@@ -40,7 +41,8 @@ def kernel_bytes(dtype):
     e = 2 if dtype == "bf16" else 4
     obs, a1, a2, a3, h = 28224, 12800 * e, 5184 * e, 3136 * e, 512 * 4
     dh = 512 * e
-    return dict(conv_fwd=obs + a1 + a2 + a3,  # a1 / a2 / a3 written once for the backward pass, nothing read back
+    return dict(conv_bwd=a2 + a1 + obs,  # dz2, a1 and the stack read once; dz1 never leaves the CU
+                conv_fwd=obs + a1 + a2 + a3,  # a1 / a2 / a3 written once for the backward pass, nothing read back
                 conv1_fwd=obs + a1, conv2_fwd=a1 + a2, conv3_fwd=a2 + a3, fc_fwd=a3 + h, fc_dgrad=dh + 2 * a3,
                 fc_wgrad=dh + a3, conv3_dgrad=a3 + 2 * a2, conv3_wgrad=a3 + a2, conv2_dgrad=a2 + 2 * a1,
                 conv2_wgrad=a2 + a1, conv1_wgrad=a1 + obs)
@@ -276,7 +278,7 @@ def run(args):
         # dominant kernel = the longest one on the update's CRITICAL PATH (main stream: forward chain, dgrad chain, conv1
         # wgrad).  The weight-gradient kernels of the second stream run in the main stream's shadow and stretch with it
         # (fc wgrad: 38 us alone, 72 us beside fc dgrad + conv3 dgrad): their timed-region durations are not a cost.
-        main_stream = ("conv_fwd", "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv2_dgrad", "conv1_wgrad")
+        main_stream = ("conv_fwd", "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc_fwd", "fc_dgrad", "conv3_dgrad", "conv_bwd", "conv2_dgrad", "conv1_wgrad")
         dom = max((k for k in table if k in main_stream), key=lambda k: trn[k][0] * trn[k][1])
         d = table[dom]
         # HBM traffic of the dominant kernel: recorded by `tests/tools/pmc_traffic.py` (rocprofv3 --pmc passes cannot run
@@ -332,8 +334,9 @@ def run(args):
             head_GBps=round((97 + 2 * 512 * 4) * B / (trn["head"][0] * 1e-3) / 1e9, 1))
         roofline["phase_wall_ms"] = {k: round(v, 3) for k, v in phase.items()}
 
-    # ---- the opt-in fused tail of the backward pass (conv2 dgrad + conv2 wgrad + conv1 wgrad in one launch,
-    # ALEPPO_OPT_FUSED_BWD; csrc/conv_bwd_fused.hpp): the same update with it on and off, alternating, same process
+    # ---- the fused tail of the backward pass (conv2 dgrad + conv2 wgrad + conv1 wgrad in one launch, the default;
+    # ALEPPO_OPT_FUSED_BWD = 0: three launches on two streams; csrc/conv_bwd_fused.hpp): the same update both ways,
+    # alternating, same process
     fused_bwd = None
     if rank == 0 and world == 1 and args.dtype == "bf16" and hasattr(pkg, "OPT_FUSED_BWD"):
         t_on, t_off = [], []
@@ -346,10 +349,10 @@ def run(args):
                 eng.train(2.5e-4, epochs, M)
                 eng.synchronize()
                 acc.append((time.perf_counter() - t0) * 1e3)
-        eng.set_option(pkg.OPT_FUSED_BWD, 0)
-        fused_bwd = dict(update_ms=round(sorted(t_on)[len(t_on) // 2], 3), update_ms_default=round(sorted(t_off)[len(t_off) // 2], 3),
-                         note="update wall time with the fused backward tail on / off (median of 4, alternating); it moves "
-                              "262 instead of 619 MB per minibatch for the three kernels it replaces (DESIGN.md 4e)")
+        eng.set_option(pkg.OPT_FUSED_BWD, 1)  # (the default)
+        fused_bwd = dict(update_ms=round(sorted(t_on)[len(t_on) // 2], 3), update_ms_three_launches=round(sorted(t_off)[len(t_off) // 2], 3),
+                         note="update wall time with the fused backward tail (default) / with the three launches it replaces "
+                              "(median of 4, alternating); 263 instead of 619 MB per minibatch (DESIGN.md 4e)")
 
     # ---- the SAME workload with the frames where a host emulator leaves them (rollout.cc:325-326): page-locked host
     # memory the ingest kernel reads in place over PCIe (ALEPPO_HOST_MAPPED).  Reported beside `value`, never as it.

@@ -303,7 +303,8 @@ typedef enum {
   ALEPPO_K_INFER_HEAD = 16, /* action head + sampling */
   ALEPPO_K_ACT_FUSED = 17,  /* frame ingest + conv1-3 of the acting batch in one launch (aleppo_step, bf16) */
   ALEPPO_K_CONV_FWD = 18,   /* conv1 -> conv2 -> conv3 of the update's forward pass in one launch (bf16) */
-  ALEPPO_K_COUNT = 19
+  ALEPPO_K_CONV_BWD = 19,   /* conv2 dgrad + conv2 wgrad + conv1 wgrad of the update's backward pass in one launch (bf16) */
+  ALEPPO_K_COUNT = 20
 } aleppo_kernel_class;
 int aleppo_profile_enable(aleppo_ctx *ctx, int on);
 int aleppo_profile_read(aleppo_ctx *ctx, int kernel_class, double *avg_ms, int64_t *launches);
@@ -326,9 +327,9 @@ typedef enum {
   ALEPPO_OPT_FUSED_FWD = 10,       /* 0: the update's forward convolutions as three launches instead of the fused
                                       conv1 -> conv2 -> conv3 kernel (bf16; same bits either way: A/B, parity tests; also
                                       the environment variable ALEPPO_FWD_FUSED at aleppo_create) */
-  ALEPPO_OPT_FUSED_BWD = 11,       /* conv2's data gradient, conv2's weight gradient and conv1's weight gradient as one launch
-                                      (bf16; dz1 stays on the CU) instead of three launches on two streams (A/B, parity
-                                      tests; environment: ALEPPO_BWD_FUSED) */
+  ALEPPO_OPT_FUSED_BWD = 11,       /* 0: conv2's data gradient, conv2's weight gradient and conv1's weight gradient as three
+                                      launches on two streams instead of the fused kernel that keeps dz1 on the CU (bf16;
+                                      A/B, parity tests; environment: ALEPPO_BWD_FUSED) */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */

@@ -11,14 +11,14 @@ Per-launch means; kernels are mapped to the bench's kernel classes by name.
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-CLASS = [("fwd_fused_kernel", "conv_fwd"), ("conv3_dgrad_tile_kernel", "conv3_dgrad"), ("LConv1Fwd", "conv1_fwd"), ("LConv2Fwd", "conv2_fwd"), ("LConv3Fwd", "conv3_fwd"), ("LConv3Dgrad", "conv3_dgrad"),
+CLASS = [("fwd_fused_kernel", "conv_fwd"), ("conv_bwd_fused_kernel", "conv_bwd"), ("conv3_dgrad_tile_kernel", "conv3_dgrad"), ("LConv1Fwd", "conv1_fwd"), ("LConv2Fwd", "conv2_fwd"), ("LConv3Fwd", "conv3_fwd"), ("LConv3Dgrad", "conv3_dgrad"),
          ("LConv2Dgrad", "conv2_dgrad"), ("conv1_wgrad_shift_kernel", "conv1_wgrad"), ("LConv1Wgrad", "conv1_wgrad"), ("LConv2Wgrad", "conv2_wgrad"),
          ("LConv3Wgrad", "conv3_wgrad"), ("gemm_pipe_kernel<0", "fc_fwd"), ("gemm_pipe_kernelILi0", "fc_fwd"),
          ("gemm_pipe_kernel<1", "fc_dgrad"), ("gemm_pipe_kernelILi1", "fc_dgrad"), ("gemm_pipe_kernel<2", "fc_wgrad"),
          ("gemm_pipe_kernelILi2", "fc_wgrad"), ("gemm_tn_kernel", "fc_wgrad"), ("head_train_kernel", "head"),
          ("adam_kernel", "adam"), ("reduce_slabs_kernel", "reduce"), ("sumsq_kernel", "sumsq")]
 # algorithmic bytes per launch at the C1 minibatch (4096 samples, H = 512): DESIGN.md section 5
-ALGO_MB = {"conv_fwd": 287.3, "conv1_fwd": 220.5, "conv2_fwd": 147.3, "conv3_fwd": 68.2, "fc_fwd": 34.1, "fc_dgrad": 55.6, "fc_wgrad": 29.9,
+ALGO_MB = {"conv_fwd": 287.3, "conv_bwd": 262.9, "conv1_fwd": 220.5, "conv2_fwd": 147.3, "conv3_fwd": 68.2, "fc_fwd": 34.1, "fc_dgrad": 55.6, "fc_wgrad": 29.9,
            "conv3_dgrad": 110.6, "conv3_wgrad": 68.2, "conv2_dgrad": 252.2, "conv2_wgrad": 147.3, "conv1_wgrad": 220.5}
 
 

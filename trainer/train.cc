@@ -535,7 +535,7 @@ public:
     static const char *names[ALEPPO_K_COUNT] = {"ingest", "gae", "head", "adam", "conv1_fwd", "conv2_fwd", "conv3_fwd",
                                                 "fc_fwd", "fc_dgrad", "fc_wgrad", "conv3_dgrad", "conv3_wgrad",
                                                 "conv2_dgrad", "conv2_wgrad", "conv1_wgrad", "reduce", "infer_head",
-                                                "act_fused", "conv_fwd"};
+                                                "act_fused", "conv_fwd", "conv_bwd"};
     for (int k = 0; k < ALEPPO_K_COUNT; ++k) {
       double ms = 0;
       int64_t n = 0;
