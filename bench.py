@@ -338,7 +338,7 @@ def run(args):
     # ALEPPO_OPT_FUSED_BWD = 0: three launches on two streams; csrc/conv_bwd_fused.hpp): the same update both ways,
     # alternating, same process
     fused_bwd = None
-    if rank == 0 and world == 1 and args.dtype == "bf16" and hasattr(pkg, "OPT_FUSED_BWD"):
+    if rank == 0 and world == 1 and args.dtype == "bf16" and hasattr(pkg, "OPT_FUSED_BWD") and not args.no_host_legs:
         t_on, t_off = [], []
         for rep in range(4):
             for on, acc in ((1, t_on), (0, t_off)):
