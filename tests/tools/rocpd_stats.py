@@ -32,7 +32,7 @@ def main(db, out, per_update=16):
         by.setdefault(short(name), []).append((e - s) / 1e3)
     total = sum(sum(v) for v in by.values())
     table = []
-    updates = max((len(v) for k, v in by.items() if "LConv1Wgrad" in k or "conv1_wgrad_shift" in k), default=0) // per_update
+    updates = max((len(v) for k, v in by.items() if "adam_kernel" in k), default=0) // per_update  # one Adam step per minibatch
     for k, v in by.items():
         iso = co = None
         if updates >= 2 and len(v) == updates * per_update:  # launched once per minibatch: an update kernel
