@@ -34,7 +34,8 @@ Tuning tuning_from_env() { // read once per context, in aleppo_create
   t.patch_conv = !flag("ALEPPO_GENERIC_CONV", false);
   t.fc_pipe = flag("ALEPPO_FC_PIPE", true);
   t.fused_fwd = flag("ALEPPO_FWD_FUSED", true);
-  t.fused_bwd = flag("ALEPPO_BWD_FUSED", true);
+  if (const char *e = std::getenv("ALEPPO_BWD_FUSED"))
+    t.fused_bwd = std::atoi(e);
   if (const char *e = std::getenv("ALEPPO_FUSED_ACT"))
     t.fused_act = std::atoi(e);
   return t;
@@ -1223,7 +1224,8 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
   const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
-  const bool bwd_fused = c->tune.fused_bwd && prec == ALEPPO_BF16 && use_patch_kernels();
+  const bool bwd_fused = (c->tune.fused_bwd == 2 || (c->tune.fused_bwd == 1 && B >= 2048)) && prec == ALEPPO_BF16 &&
+                         use_patch_kernels();
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
   // (Tried in round 3, tests/tools/forkbench.hip: in isolation an event record + wait costs the pair of streams ~12 us
   // per dependency, a one-wave signal kernel + a one-wave gate kernel on a device word ~3 us.  In the update it changes
@@ -1711,7 +1713,7 @@ extern "C" int aleppo_set_option(aleppo_ctx *c, int option, int value) {
   else if (option == ALEPPO_OPT_FUSED_FWD)
     c->tune.fused_fwd = value != 0;
   else if (option == ALEPPO_OPT_FUSED_BWD)
-    c->tune.fused_bwd = value != 0;
+    c->tune.fused_bwd = value; // 0: never, 1: at minibatches >= 2048 samples (default), 2: always
   else if (option == ALEPPO_OPT_DEBUG_NO_PUBLISH)
     c->dbg_no_publish = value != 0;
   else if (option == ALEPPO_OPT_SERIAL_UPDATE)

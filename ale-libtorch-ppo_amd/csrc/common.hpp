@@ -61,7 +61,8 @@ struct Tuning {
   bool patch_conv = true;     // sample-stationary bf16 conv kernels (false: generic gather-GEMMs)
   bool fc_pipe = true;        // pipelined LDS-DMA fc GEMMs at minibatch sizes > 256
   bool fused_fwd = true;      // the update's conv1 -> conv2 -> conv3 forward as one launch (conv_fwd_fused.hpp)
-  bool fused_bwd = true;      // conv2 dgrad + conv2 wgrad + conv1 wgrad as one launch (conv_bwd_fused.hpp)
+  int fused_bwd = 1;          // conv2 dgrad + conv2 wgrad + conv1 wgrad as one launch (conv_bwd_fused.hpp): 0 never, 1 at
+                              // minibatches >= 2048 samples (below, its fixed costs outweigh the bytes: v1.yaml's 1280), 2 always
   int fused_act = 1;          // frame ingest fused in front of the acting convolutions: 0 never, 1 where faster, 2 always
 };
 const Tuning &tuning();

@@ -341,7 +341,7 @@ def run(args):
     if rank == 0 and world == 1 and args.dtype == "bf16" and hasattr(pkg, "OPT_FUSED_BWD") and not args.no_host_legs:
         t_on, t_off = [], []
         for rep in range(4):
-            for on, acc in ((1, t_on), (0, t_off)):
+            for on, acc in ((2, t_on), (0, t_off)):
                 eng.set_option(pkg.OPT_FUSED_BWD, on)
                 eng.train(2.5e-4, epochs, M)
                 eng.synchronize()

@@ -327,9 +327,10 @@ typedef enum {
   ALEPPO_OPT_FUSED_FWD = 10,       /* 0: the update's forward convolutions as three launches instead of the fused
                                       conv1 -> conv2 -> conv3 kernel (bf16; same bits either way: A/B, parity tests; also
                                       the environment variable ALEPPO_FWD_FUSED at aleppo_create) */
-  ALEPPO_OPT_FUSED_BWD = 11,       /* 0: conv2's data gradient, conv2's weight gradient and conv1's weight gradient as three
-                                      launches on two streams instead of the fused kernel that keeps dz1 on the CU (bf16;
-                                      A/B, parity tests; environment: ALEPPO_BWD_FUSED) */
+  ALEPPO_OPT_FUSED_BWD = 11,       /* conv2's data gradient, conv2's weight gradient and conv1's weight gradient as ONE launch that
+                                      keeps dz1 on the CU (bf16): 0 never (three launches on two streams: A/B, parity
+                                      tests), 1 at minibatches of >= 2048 samples (default), 2 always; environment:
+                                      ALEPPO_BWD_FUSED */
   ALEPPO_OPT_UPDATE_GRAPH = 7      /* 1: capture the epochs x minibatches loop of aleppo_train in a hipGraph and replay it
                                       (capture_train_cuda_graph, src/ai/ppo/train.h:163-195); lr and the Adam bias
                                       corrections are device scalars, so a replay follows the annealed rate */

@@ -364,7 +364,7 @@ def test_bf16_fused_backward_matches_the_three_launches(pkg, N, A):
     adv, ret = hf.hf_range(734, (N,), -1, 1), hf.hf_range(735, (N,), -1, 1)
     masks = (hf.hf_unit(736, N) >= np.float32(0.1)).astype(np.uint8)
     res = {}
-    for fused in (1, 0):
+    for fused in (2, 0):  # (2: also below the 2048-sample minibatches the default fuses at)
         eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
         eng.set_option(pkg.OPT_FUSED_BWD, fused)
         assert eng.get_option(pkg.OPT_FUSED_BWD) == fused
@@ -375,7 +375,7 @@ def test_bf16_fused_backward_matches_the_three_launches(pkg, N, A):
         m2 = eng.train(2.5e-4, 1, M)
         res[fused] = (m1["loss"], m1["grad_norm"], g, m2["loss"], eng.export_params())
         eng.close()
-    (l1, n1, g1, k1, p1), (l0, n0, g0, k0, p0) = res[1], res[0]
+    (l1, n1, g1, k1, p1), (l0, n0, g0, k0, p0) = res[2], res[0]
     assert np.array_equal(l1, l0)  # the forward pass is untouched
     np.testing.assert_allclose(n1, n0, rtol=1e-6)
     o = 0

@@ -15,7 +15,7 @@ old_lp = np.log(np.full((N, A), 1.0 / A, np.float32))
 adv, ret = hf.hf_range(714, (N,), -1, 1), hf.hf_range(715, (N,), -1, 1)
 masks = np.ones(N, np.uint8)
 res = {}
-for fused in (0, 1):
+for fused in (0, 2):
     eng = pkg.Engine(N // 8, 8, A, H, precision=pkg.BF16)
     eng.set_option(pkg.OPT_FUSED_BWD, fused)
     eng.load_params(params)
@@ -23,8 +23,8 @@ for fused in (0, 1):
     m = eng.train(2.5e-4, 1, M)
     res[fused] = (m["loss"], m["grad_norm"], eng.export_grads())
     eng.close()
-print("loss", res[0][0], res[1][0]); print("norm", res[0][1], res[1][1])
-g0, g1 = res[0][2], res[1][2]
+print("loss", res[0][0], res[2][0]); print("norm", res[0][1], res[2][1])
+g0, g1 = res[0][2], res[2][2]
 # reference order: conv1.w 8192, b 32, conv2.w 32768, b 64, conv3.w 36864, b 64, fc.w, fc.b, heads
 sizes = [("w1", 32 * 4 * 8 * 8), ("b1", 32), ("w2", 64 * 32 * 16), ("b2", 64), ("w3", 64 * 64 * 9), ("b3", 64), ("wfc", 512 * 3136), ("bfc", 512)]
 o = 0
