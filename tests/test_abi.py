@@ -114,3 +114,29 @@ def test_option_and_location_constants_match_the_header(pkg):
         assert m and int(m.group(1)) == val, name
     kc = re.search(r"ALEPPO_K_COUNT = (\d+)", txt)
     assert int(kc.group(1)) == len(pkg.KERNEL_CLASSES)
+
+
+@pytest.mark.gpu
+def test_bench_line_keeps_the_contract():
+    """`python bench.py` (short: 2 steps, no CPU baseline / host legs / v1 leg) prints ONE JSON line with the keys the driver
+    reads, the dominant kernel's roofline block (achieved / peak = frac, algorithmic bytes, the kernel-source stamp) and - on a
+    1-GPU bf16 run with the legs on - the fused-backward option leg."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-host-legs", "--no-v1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "env-steps/s" and d["value"] > 0
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "kernel_source_sha16"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["kernel"] in rf["update_kernels"] and rf["update_kernels"][rf["kernel"]]["ms"] > 0
