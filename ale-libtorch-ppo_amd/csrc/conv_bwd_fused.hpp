@@ -239,7 +239,6 @@ __global__ __launch_bounds__(cb::NT) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // =========================================================== P0: dz2 -> I1 + I2, a1 -> I3
     FFWaitVm<7, 10>::wait(RA); // behind these loads: the 7 stack loads
     if constexpr (!(ABL & 8)) {
-      const bool counts = true;
       int zs; // (opaque zero: the ~20 staging addresses are recomputed per sample instead of living in registers)
       asm volatile("v_mov_b32 %0, 0" : "=v"(zs));
       const int tidz = tid + zs;
@@ -250,12 +249,11 @@ __global__ __launch_bounds__(cb::NT) __attribute__((amdgpu_waves_per_eu(1, 1))) 
           const int p = v >> 3, part = v & 7, oy = p / 9, ox = p - oy * 9;
           *reinterpret_cast<u32x4 *>(sA + (oy + 1) * PR1 + (ox + 1) * CP1 + part * 8) = RA[i];
           *reinterpret_cast<u32x4 *>(sA + I1_ELEMS + p * T2S + part * 8) = RA[i];
-          if (counts)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              bsum[2 * e] += bf16_bits_to_f32(RA[i][e] & 0xFFFFu);
-              bsum[2 * e + 1] += bf16_bits_to_f32(RA[i][e] >> 16);
-            }
+          for (int e = 0; e < 4; ++e) { // db2
+            bsum[2 * e] += bf16_bits_to_f32(RA[i][e] & 0xFFFFu);
+            bsum[2 * e + 1] += bf16_bits_to_f32(RA[i][e] >> 16);
+          }
         }
       }
 #pragma unroll

@@ -6,6 +6,7 @@
 #include "conv3_tile.hpp"
 #include "conv_fwd_fused.hpp"
 #include "conv_bwd_fused.hpp"
+#include <cstdio>
 #include <cstdlib>
 
 namespace aleppo {
@@ -21,6 +22,15 @@ static int num_cus() {
       n = 256;
   }
   return n;
+}
+
+// developer switches that select timing-only variants of the fused kernels (a phase left out: WRONG results): say so, loudly
+static int ablation_switch(const char *name) {
+  const char *e = std::getenv(name);
+  const int v = e ? std::atoi(e) : 0;
+  if (v)
+    std::fprintf(stderr, "aleppo: %s=%d selects a TIMING-ONLY kernel variant: the update's results are WRONG\n", name, v);
+  return v;
 }
 
 template <class K> static void allow_smem(K kernel, size_t bytes) {
@@ -87,7 +97,7 @@ void patch_fwd_fused(hipStream_t s, const uint32_t *obs, SampleMap map, const vo
   FwdFusedParams P{obs, map, static_cast<const bf16 *>(W1), static_cast<const bf16 *>(W2), static_cast<const bf16 *>(W3),
                    b1,  b2,  b3, static_cast<bf16 *>(a1), static_cast<bf16 *>(a2), static_cast<bf16 *>(a3), ns};
   // ALEPPO_FF_ABLATE: timing-only builds of the kernel with one part left out (wrong results)
-  static const int abl = std::getenv("ALEPPO_FF_ABLATE") ? std::atoi(std::getenv("ALEPPO_FF_ABLATE")) : 0;
+  static const int abl = ablation_switch("ALEPPO_FF_ABLATE");
   switch (abl) {
   case 1: return launch_fwd_fused<1>(s, P);
   case 2: return launch_fwd_fused<2>(s, P);
@@ -112,7 +122,7 @@ int patch_conv_bwd_fused(hipStream_t s, const void *dz2, const void *a1, const u
                   sw2, sb2, sw1, sb1, ns, 1.0f / 255.0f};
   const int grid = (int)std::min<long>(ns, std::min(num_cus(), std::min(MAXS_C1, MAXS_C2)));
   // ALEPPO_CB_ABLATE: timing-only builds of the kernel with one part left out (wrong results)
-  static const int abl = std::getenv("ALEPPO_CB_ABLATE") ? std::atoi(std::getenv("ALEPPO_CB_ABLATE")) : 0;
+  static const int abl = ablation_switch("ALEPPO_CB_ABLATE");
   switch (abl) {
   case 1: launch_conv_bwd<1>(s, P, grid); break;
   case 2: launch_conv_bwd<2>(s, P, grid); break;
