@@ -1224,8 +1224,11 @@ extern "C" int aleppo_train(aleppo_ctx *c, double lr, int epochs, int M, aleppo_
     return !(e && std::atoi(e) == 1); // ALEPPO_BWD_STREAMS=1: everything on one stream (A/B testing: 8.80 ms)
   }();
   const bool two = two_env && !c->serial_update; // (profiling brackets every kernel on the stream it runs on)
+  // (Not with data parallelism: the fused kernel's 512-register workgroups need whole CUs, and bucket 0's all-reduce - whose
+  // RCCL kernels are resident on some of them by the time the dgrad chain gets there - is what the conv backward is meant to
+  // run BESIDE; the three launches share CUs with it, the fused kernel's workgroups on those CUs would start when it ends.)
   const bool bwd_fused = (c->tune.fused_bwd == 2 || (c->tune.fused_bwd == 1 && B >= 2048)) && prec == ALEPPO_BF16 &&
-                         use_patch_kernels();
+                         use_patch_kernels() && !dp;
   hipStream_t sw = two ? c->wg_stream : s; // stream of the weight-gradient kernels
   // (Tried in round 3, tests/tools/forkbench.hip: in isolation an event record + wait costs the pair of streams ~12 us
   // per dependency, a one-wave signal kernel + a one-wave gate kernel on a device word ~3 us.  In the update it changes

@@ -662,6 +662,8 @@ def test_rccl_path_at_benched_size_with_one_rank_communicator(pkg):
         if comm:
             eng.comm_init(pkg.Engine.comm_unique_id())
             eng.set_option(pkg.OPT_FORCE_COMM, 1)
+        else:  # (the data-parallel schedule keeps the backward tail as three launches: compare like with like)
+            eng.set_option(pkg.OPT_FUSED_BWD, 0)
         eng.load_params(params)
         eng.set_batch(obs, actions, old_lp, adv, ret, masks)
         m = eng.train(2.5e-4, 2, M)
