@@ -196,3 +196,19 @@ for pad in range(0, 8):
             tot += cyc(ad)
             n += 1
     print(pad, pitch, tot / n)
+
+# ---- conv_bwd_fused.hpp, phase P1: the zero-bordered 11 x 11 image of dz2 read by the conv2 dgrad (one parity class = a
+# 10 x 10 cell grid per wave, 7 pixel atoms): pixel pitch CP / row pitch PR candidates.  (80, 928) is what the kernel uses.
+def fused_bwd_dz2_image(CP, PR):
+    tot = 0
+    for atom in range(7):
+        ad = []
+        for lane in range(64):
+            fr = lane & 15; fg = lane >> 4
+            q = min(atom * 16 + fr, 99); Y = q // 10; X = q % 10
+            ad.append((Y * PR + X * CP + fg * 8) * 2)
+        tot += cyc(ad)
+    return tot / 7
+print("---- fused backward tail, dz2 image (LDS cycles per ds_read_b128; 4.0 = conflict-free)")
+for CP, PR in ((72, 848), (80, 928), (80, 1056), (112, 1248), (96, 1072)):
+    print("CP", CP, "PR", PR, "%.2f" % fused_bwd_dz2_image(CP, PR))
